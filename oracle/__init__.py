@@ -1,0 +1,31 @@
+"""
+oracle/ -- CPU restatement of GaPFlow's explicit time-integration hot path.
+
+THIS PACKAGE IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import it; nothing under ``gapflow_amd/`` does.  It restates,
+in plain NumPy/SciPy, the arithmetic of the reference path
+
+    GaPFlow/problem.py:509-586   (MacCormack step, residual, dt)
+    GaPFlow/problem.py:676-768   (ghost-cell boundary conditions)
+    GaPFlow/integrate.py:38-198  (flux / source assembly)
+    GaPFlow/models/{pressure,sound,viscous,viscosity,stress}.py (closures)
+    GaPFlow/topography.py:38-255 (gap profiles)
+    GaPFlow/io.py:128-445        (YAML sanitisation)
+    GaPFlow/models/gp.py:509-603 (Matern-3/2 GP surrogate; tinygp semantics)
+
+Pinning status
+--------------
+* Fixed-form path: PINNED.  ``tests/golden/make_golden.py`` (run in the build
+  container only) loads the reference's pure-NumPy leaf modules by file path
+  (integrate.py, models/viscous.py, pressure.py, sound.py, viscosity.py),
+  checks every oracle leaf function against them and freezes their outputs as
+  ``tests/golden/*.npz``; the reference's own analytic tests
+  (test_sommerfeld, test_wave_decay, test_mass_conservation, test_flip_axes,
+  test_analytic) are re-run against the oracle in ``tests/``.
+* GP path: PARITY UNPINNED.  tinygp / jax / jaxopt are not installed and the
+  reference's only numeric GP test is a self-consistency check
+  (tests/test_inference.py:88-111).  ``oracle/gp.py`` restates the published
+  Matern-3/2 + Cholesky formulas; see its header.
+"""

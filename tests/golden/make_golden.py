@@ -1,0 +1,351 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the reference's own leaf modules.
+
+Runs ONLY in the build container (it reads /root/reference); the fixtures it
+writes are plain data (.npz: inputs + expected outputs) and are committed.
+
+What is a *true reference output* here: the reference's pure-NumPy leaf modules
+
+    GaPFlow/integrate.py, GaPFlow/models/{viscous,pressure,sound,viscosity}.py
+
+are loaded by file path (the package __init__ needs jax/muGrid, which are not
+installed) and evaluated on seeded random fields -> ``leaf_*.npz``.
+
+Step-level fixtures (``step_*.npz``) drive those same reference leaf functions
+in the order of GaPFlow/problem.py:509-586 through oracle/problem.py's
+restated orchestration (problem.py itself needs muGrid and cannot be imported).
+Before anything is written, every oracle leaf function is checked against the
+reference leaf function on the same inputs (rtol 1e-13), and every step-level
+run is repeated with the oracle's own leaf functions and compared (rtol 1e-11).
+
+    python tests/golden/make_golden.py
+"""
+import importlib.util
+import os
+import sys
+import types
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference/GaPFlow/'
+sys.path.insert(0, ROOT)
+
+import oracle.closures as ocl            # noqa: E402
+import oracle.integrate as oint          # noqa: E402
+import oracle.problem as oprob           # noqa: E402
+from oracle.problem import OracleProblem  # noqa: E402
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+ref_int = _load('ref_integrate', REF + 'integrate.py')
+ref_visc = _load('ref_viscous', REF + 'models/viscous.py')
+ref_pres = _load('ref_pressure', REF + 'models/pressure.py')
+ref_snd = _load('ref_sound', REF + 'models/sound.py')
+ref_vsc = _load('ref_viscosity', REF + 'models/viscosity.py')
+
+EOS_PROPS = {
+    'DH': dict(EOS='DH', rho0=877.7007, P0=101325., C1=3.5e10, C2=1.23),
+    'PL': dict(EOS='PL', rho0=1.1853, P0=101325., alpha=0.),
+    'vdW': dict(EOS='vdW', M=39.948, T=100., a=1.355, b=0.03201),
+    'MT': dict(EOS='MT', rho0=700., P0=0.101e6, K=0.557e9, n=7.33),
+    'cubic': dict(EOS='cubic', a=1.33030e-1, b=-1.41778e2, c=8.35134e4, d=-2.86532e6),
+    'BWR': dict(EOS='BWR', T=1.0, gamma=3.0),
+    'Bayada': dict(EOS='Bayada', rho_l=850., rho_v=0.019, c_l=1600., c_v=352.),
+}
+EOS_RHO = {'DH': (800., 1100.), 'PL': (0.5, 2.0), 'vdW': (1., 150.), 'MT': (600., 800.),
+           'cubic': (700., 800.), 'BWR': (0.05, 0.9), 'Bayada': (0.001, 900.)}
+
+
+def check(a, b, rtol, what):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    assert np.array_equal(np.isnan(a), np.isnan(b)), f"{what}: NaN pattern differs"
+    a, b = a[~np.isnan(b)], b[~np.isnan(b)]
+    scale = np.maximum(np.abs(b), np.max(np.abs(b)) * 1e-3 + 1e-300)
+    err = np.max(np.abs(a - b) / scale) if a.size else 0.
+    assert err <= rtol, f"{what}: oracle vs reference rel err {err:.3e} > {rtol}"
+    return err
+
+
+def leaf_fixtures():
+    rng = np.random.default_rng(20260313)
+    out = {}
+    # --- EOS and sound speed ------------------------------------------------
+    for name, prop in EOS_PROPS.items():
+        lo, hi = EOS_RHO[name]
+        rho = rng.uniform(lo, hi, size=(7, 9))
+        p_ref = ref_pres.eos_pressure(rho.copy(), prop)
+        c_ref = ref_snd.eos_sound_velocity(rho.copy(), prop)
+        check(ocl.eos_pressure(rho, prop), p_ref, 1e-13, f'eos_pressure[{name}]')
+        check(ocl.eos_sound_speed(rho, prop), c_ref, 1e-13, f'eos_sound[{name}]')
+        out[f'eos_{name}_rho'], out[f'eos_{name}_p'], out[f'eos_{name}_c'] = rho, p_ref, c_ref
+    # --- viscous stresses, slip='top', grad q = 0, per-cell slip length -------
+    shape = (6, 8)
+    q = np.stack([rng.uniform(800., 950., shape), rng.uniform(-60., 60., shape), rng.uniform(-40., 40., shape)])
+    h = np.stack([rng.uniform(1e-6, 7e-5, shape), rng.uniform(-2e-3, 2e-3, shape), rng.uniform(-2e-3, 2e-3, shape)])
+    for tag, Ls in (('Ls0', np.zeros((1,) + shape)), ('LsF', rng.uniform(0., 5e-6, (1,) + shape))):
+        U, V, eta, zeta = 0.1, -0.07, 0.0794, 0.013
+        b = ref_visc.stress_bottom(q, h, U, V, eta, zeta, Ls)
+        t = ref_visc.stress_top(q, h, U, V, eta, zeta, Ls)
+        a = ref_visc.stress_avg(q, h, U, V, eta, zeta, Ls)
+        check(ocl.stress_bottom(q, h, U, V, eta, zeta, Ls[0]), b, 1e-13, 'stress_bottom ' + tag)
+        check(ocl.stress_top(q, h, U, V, eta, zeta, Ls[0]), t, 1e-12, 'stress_top ' + tag)
+        check(ocl.stress_avg(q, h, U, V, eta, zeta, Ls[0]), a, 1e-12, 'stress_avg ' + tag)
+        out[f'visc_{tag}_Ls'], out[f'visc_{tag}_bot'], out[f'visc_{tag}_top'], out[f'visc_{tag}_avg'] = Ls, b, t, a
+    out['visc_q'], out['visc_h'] = q, h
+    out['visc_params'] = np.array([0.1, -0.07, 0.0794, 0.013])
+    # --- flux differences and source ---------------------------------------
+    p = rng.uniform(1e5, 3e5, shape)
+    tau = rng.normal(size=(3,) + shape)
+    lower = rng.normal(size=(6,) + shape)
+    upper = rng.normal(size=(6,) + shape)
+    topo = np.concatenate([h, np.zeros((1,) + shape)])
+    for d in (1, -1):
+        fx, fy = ref_int.predictor_corrector(q, p, tau, d)
+        ox, oy = oint.predictor_corrector(q, p, tau, d)
+        check(ox, fx, 1e-15, 'flux_x')
+        check(oy, fy, 1e-15, 'flux_y')
+        out[f'flux_d{d:+d}_x'], out[f'flux_d{d:+d}_y'] = fx, fy
+    s = ref_int.source(q, topo, tau, lower, upper)
+    check(oint.source(q, topo, tau, lower, upper), s, 1e-15, 'source')
+    out.update(flux_p=p, flux_tau=tau, src_lower=lower, src_upper=upper, src_topo=topo, src_out=s)
+    # --- viscosity laws ------------------------------------------------------
+    pz = {'Barus': dict(name='Barus', aB=20e-9), 'Roelands': dict(name='Roelands', mu_inf=1e-3, p_ref=1.96e8, z=0.68),
+          'Dukler': dict(name='Dukler', eta_v=3.9e-5, rho_l=850., rho_v=0.019),
+          'McAdams': dict(name='McAdams', eta_v=3.9e-5, rho_l=850., rho_v=0.019)}
+    pp = rng.uniform(1e5, 5e8, 20)
+    rr = rng.uniform(1., 850., 20)
+    for k, d in pz.items():
+        arg = rr if k in ('Dukler', 'McAdams') else pp
+        r = ref_vsc.piezoviscosity(arg, 0.0794, d)
+        check(ocl.piezoviscosity(arg, 0.0794, d), r, 1e-14, 'piezo ' + k)
+        out[f'piezo_{k}'] = r
+    out['piezo_p'], out['piezo_rho'] = pp, rr
+    th = {'Eyring': dict(name='Eyring', tauE=5e5), 'Carreau': dict(name='Carreau', mu_inf=1e-9, lam=1e-6, a=2., N=0.6)}
+    sr = rng.uniform(1e3, 1e8, 20)
+    for k, d in th.items():
+        r = ref_vsc.shear_thinning_factor(sr, 0.0794, d)
+        check(ocl.shear_thinning_factor(sr, 0.0794, d), r, 1e-14, 'thinning ' + k)
+        out[f'thin_{k}'] = r
+    out['thin_sr'] = sr
+    gx, gy, hh = rng.normal(size=20) * 1e9, rng.normal(size=20) * 1e9, rng.uniform(1e-6, 1e-5, 20)
+    r = ref_vsc.shear_rate_avg(gx, gy, hh, 0.1, 0., 0.0794)
+    check(ocl.shear_rate_avg(gx, gy, hh, 0.1, 0., 0.0794), r, 1e-14, 'shear_rate_avg')
+    out.update(sr_gx=gx, sr_gy=gy, sr_h=hh, sr_out=r)
+    np.savez_compressed(os.path.join(HERE, 'leaf_closures.npz'), **out)
+    print('leaf_closures.npz:', len(out), 'arrays')
+
+
+# ---------------------------------------------------------------------------
+# Step-level fixtures: reference leaf arithmetic + restated orchestration
+# ---------------------------------------------------------------------------
+
+def reference_leaf_table():
+    """Namespace with oracle.closures' names bound to the reference's functions."""
+    ns = types.SimpleNamespace()
+    ns.eos_pressure = ref_pres.eos_pressure
+    ns.eos_sound_speed = ref_snd.eos_sound_velocity
+    ns.stress_bottom = lambda q, h, U, V, eta, zeta, Ls: ref_visc.stress_bottom(q, h, U, V, eta, zeta, Ls[None])
+    ns.stress_top = lambda q, h, U, V, eta, zeta, Ls: ref_visc.stress_top(q, h, U, V, eta, zeta, Ls[None])
+    ns.stress_avg = lambda q, h, U, V, eta, zeta, Ls: ref_visc.stress_avg(q, h, U, V, eta, zeta, Ls[None])
+    ns.piezoviscosity = ref_vsc.piezoviscosity
+    ns.shear_rate_avg = ref_vsc.shear_rate_avg
+    ns.shear_thinning_factor = ref_vsc.shear_thinning_factor
+    return ns
+
+
+class use_reference_leaves:
+    def __enter__(self):
+        self.saved = (oprob.cl, oprob.predictor_corrector, oprob.source)
+        oprob.cl = reference_leaf_table()
+        oprob.predictor_corrector = ref_int.predictor_corrector
+        oprob.source = ref_int.source
+
+    def __exit__(self, *a):
+        oprob.cl, oprob.predictor_corrector, oprob.source = self.saved
+
+
+def _yaml(path, start, end):
+    lines = open(path).read().split('\n')
+    return '\n'.join(lines[start - 1:end])
+
+
+def _testsim(name):
+    return open(f'/root/reference/tests/{name}').read().split('sim = """')[1].split('"""')[0]
+
+
+CASES = {}
+
+# cfg1: the README's "examples/journal.yaml" snippet (README.md:73-108): D/N/N in x, fixed dt, 200 steps
+CASES['journal1d_readme'] = dict(yaml=_yaml('/root/reference/README.md', 74, 107).replace('write_freq: 10', 'write_freq: 10\n    silent: True'),
+                                 snaps=[1, 10, 200])
+# examples/config/journal_1d_dowson-higginson.yaml: periodic, adaptive CFL 0.25
+CASES['journal1d_periodic'] = dict(yaml=open('/root/reference/examples/config/journal_1d_dowson-higginson.yaml').read(),
+                                   snaps=[1, 10, 300])
+# tests/test_mass_conservation.py: 50x50 all-periodic journal, 50 steps
+CASES['journal2d_periodic50'] = dict(yaml=_testsim('test_mass_conservation.py'), snaps=[1, 50])
+# tests/test_flip_axes.py geometry, flipped (V-driven), 40x40 to stay small
+CASES['journal2d_flip40'] = dict(yaml=_testsim('test_flip_axes.py').replace('Nx: 100', 'Nx: 40').replace('Ny: 100', 'Ny: 40'),
+                                 snaps=[1, 5], flip=True)
+# tests/test_wave_decay.py: cubic EOS, flat gap, fixed dt, sound wave n=2 seeded into jx
+CASES['wave_decay_cubic'] = dict(yaml=_testsim('test_wave_decay.py'), snaps=[1, 100], wave=2)
+# cfg2 geometry scaled down: inclined slider 64x48, D/N/N in x and in y, DH, adaptive CFL 0.4, V != 0, MC_order 0
+CASES['slider2d_dn'] = dict(yaml="""
+options:
+    silent: True
+grid:
+    Lx: 0.1
+    Ly: 0.075
+    Nx: 64
+    Ny: 48
+    xE: ['D', 'N', 'N']
+    xW: ['D', 'N', 'N']
+    yS: ['D', 'N', 'N']
+    yN: ['D', 'N', 'N']
+    xE_D: 877.7007
+    xW_D: 870.
+    yS_D: 880.
+    yN_D: 875.
+geometry:
+    type: inclined
+    hmax: 6.6e-5
+    hmin: 1.e-5
+    U: 50.
+    V: 5.
+numerics:
+    CFL: 0.4
+    adaptive: 1
+    MC_order: 0
+    max_it: 100
+properties:
+    shear: 0.0794
+    bulk: 0.02
+    EOS: DH
+    rho0: 877.7007
+""", snaps=[1, 2, 25])
+# asperity (2-D profile, ghost topography differs from the periodic image), periodic, slip-length field, MC_order -1
+CASES['asperity2d_slip'] = dict(yaml="""
+options:
+    silent: True
+grid:
+    Lx: 1.e-3
+    Ly: 1.e-3
+    Nx: 48
+    Ny: 40
+geometry:
+    type: asperity
+    hmin: 2.e-6
+    hmax: 1.e-5
+    num: 1
+    U: 1.
+    V: 0.5
+numerics:
+    CFL: 0.3
+    adaptive: 1
+    MC_order: -1
+    max_it: 100
+properties:
+    shear: 0.0794
+    bulk: 0.
+    EOS: DH
+    rho0: 877.7007
+""", snaps=[1, 20], slip=True)
+# remaining EOS on a 1-D parabolic slider (geometry of tests/test_inference.py), D/N BCs
+for _eos, _extra, _rho0, _dt in (('BWR', 'T: 1.0', 0.8, 0.05), ('PL', 'P0: 101325.\n    alpha: 0.', 1.1853, 0.05),
+                                 ('MT', '', 700., 1e-3), ('vdW', '', 50., 0.05), ('Bayada', '', 850., 1e-3)):
+    CASES[f'parabolic1d_{_eos}'] = dict(yaml=f"""
+options:
+    silent: True
+grid:
+    Lx: 1470.
+    Ly: 1.
+    Nx: 80
+    Ny: 1
+    xE: ['D', 'N', 'N']
+    xW: ['D', 'N', 'N']
+    xE_D: {_rho0}
+    xW_D: {_rho0}
+geometry:
+    type: parabolic
+    hmin: 12.
+    hmax: 60.
+    U: 0.12
+    V: 0.
+numerics:
+    CFL: 0.5
+    adaptive: 1
+    dt: {_dt}
+    max_it: 100
+properties:
+    shear: 2.15
+    bulk: 0.
+    EOS: {_eos}
+    rho0: {_rho0}
+    {_extra}
+""", snaps=[1, 30])
+
+
+def run_case(name, spec, use_ref):
+    prob = OracleProblem.from_string(spec['yaml'])
+    if spec.get('flip'):
+        prob = OracleProblem.from_dict(_flipped(spec['yaml']))
+    if spec.get('slip'):
+        rng = np.random.default_rng(7)
+        prob.extra[0] = rng.uniform(0., 2e-6, prob.extra[0].shape)
+    prob._pre_run()
+    if spec.get('wave'):
+        kn = spec['wave'] * 2. * np.pi / prob.grid['Lx']
+        prob.q[1, 1:-1, :] = np.sin(kn * prob.x[1:-1, 1])[:, None]       # tests/test_wave_decay.py:127-129
+        prob.kinetic_energy_old = prob.kinetic_energy
+    res = {'q_init': prob.q.copy(), 'extra': prob.extra.copy(), 'topo': prob.topo.copy()}
+    hist = []
+    for s in range(1, max(spec['snaps']) + 1):
+        prob.update()
+        hist.append([prob.step, prob.simtime, prob.dt, prob.kinetic_energy, prob.residual, prob.v_sound, prob.v_max, prob.mass])
+        if s in spec['snaps']:
+            prob.update_closures()
+            res[f'q_{s}'] = prob.q.copy()
+            res[f'p_{s}'] = prob.pressure.copy()
+    res['history'] = np.array(hist)     # columns: step, time, dt(next), ekin, residual, vsound, vmax, mass
+    return res
+
+
+def _flipped(yaml_text):
+    import io as _io
+    from oracle.config import read_yaml_input
+    d = read_yaml_input(_io.StringIO(yaml_text))
+    d['geometry']['V'] = d['geometry']['U']     # tests/test_flip_axes.py:73-76
+    d['geometry']['U'] = 0.
+    d['geometry']['flip'] = True
+    return d
+
+
+def step_fixtures():
+    for name, spec in CASES.items():
+        with use_reference_leaves():
+            ref = run_case(name, spec, True)
+        own = run_case(name, spec, False)
+        worst = 0.
+        for k in ref:
+            if k.startswith('q_') or k.startswith('p_') or k == 'history':
+                cols = slice(None)
+                if k == 'history':      # residual (col 4) is ill-conditioned, SURVEY H1: compare the rest
+                    r, o = np.delete(ref[k], 4, axis=1), np.delete(own[k], 4, axis=1)
+                else:
+                    r, o = ref[k], own[k]
+                worst = max(worst, check(o, r, 1e-10, f'{name}:{k}'))
+        ref['yaml'] = np.array(spec['yaml'])
+        ref['meta'] = np.array(repr({k: v for k, v in spec.items() if k != 'yaml'}))
+        np.savez_compressed(os.path.join(HERE, f'step_{name}.npz'), **ref)
+        print(f'step_{name}.npz: oracle-vs-reference-leaves worst rel err {worst:.2e}')
+
+
+if __name__ == '__main__':
+    leaf_fixtures()
+    step_fixtures()
