@@ -1,0 +1,112 @@
+"""ctypes binding of libgapflow_hip.so (include/gapflow_hip.h).
+
+There is deliberately no fallback: if the HIP library is missing or no MI355X is visible,
+every compute entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'libgapflow_hip.so')
+
+EOS_IDS = {'DH': 0, 'PL': 1, 'vdW': 2, 'MT': 3, 'cubic': 4, 'BWR': 5, 'Bayada': 6}
+EOS_KEYS = {'DH': ['rho0', 'P0', 'C1', 'C2'], 'PL': ['rho0', 'P0', 'alpha'], 'vdW': ['M', 'T', 'a', 'b'],
+            'MT': ['rho0', 'P0', 'K', 'n'], 'cubic': ['a', 'b', 'c', 'd'], 'BWR': ['T', 'gamma'],
+            'Bayada': ['rho_l', 'rho_v', 'c_l', 'c_v']}
+PIEZO_IDS = {'Barus': 1, 'Roelands': 2, 'Dukler': 3, 'McAdams': 4}
+PIEZO_KEYS = {'Barus': ['aB'], 'Roelands': ['mu_inf', 'p_ref', 'z'], 'Dukler': ['eta_v', 'rho_l', 'rho_v'],
+              'McAdams': ['eta_v', 'rho_l', 'rho_v']}
+BC_P, BC_D, BC_N = 0, 1, 2
+FIELD_Q, FIELD_TOPO, FIELD_EXTRA, FIELD_PRESSURE, FIELD_TAU_AVG, FIELD_WALL_LOWER, FIELD_WALL_UPPER = range(7)
+FIELD_NCOMP = {FIELD_Q: 3, FIELD_TOPO: 3, FIELD_EXTRA: 1, FIELD_PRESSURE: 1, FIELD_TAU_AVG: 3,
+               FIELD_WALL_LOWER: 6, FIELD_WALL_UPPER: 6}
+
+
+class GpfConfig(C.Structure):
+    _fields_ = [('Nx', C.c_int32), ('Ny', C.c_int32), ('dx', C.c_double), ('dy', C.c_double),
+                ('U', C.c_double), ('V', C.c_double), ('eta', C.c_double), ('zeta', C.c_double),
+                ('eos', C.c_int32), ('eos_par', C.c_double * 8),
+                ('piezo', C.c_int32), ('piezo_par', C.c_double * 4),
+                ('bc_rule', (C.c_int32 * 3) * 4), ('bc_value', C.c_double * 4),
+                ('halo_lo', C.c_int32), ('halo_hi', C.c_int32),
+                ('adaptive', C.c_int32), ('CFL', C.c_double), ('dt_fixed', C.c_double), ('tol', C.c_double),
+                ('max_it', C.c_int64), ('mc_order', C.c_int32), ('device', C.c_int32)]
+
+
+class GpfScalars(C.Structure):
+    _fields_ = [('step', C.c_int64), ('simtime', C.c_double), ('dt', C.c_double), ('ekin', C.c_double),
+                ('ekin_old', C.c_double), ('residual', C.c_double), ('v_max', C.c_double), ('v_sound', C.c_double),
+                ('mass', C.c_double), ('invalid', C.c_int32), ('converged', C.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/gapflow_hip.h
+_DP = C.POINTER(C.c_double)
+_VPP = C.POINTER(C.c_void_p)
+SIGNATURES = {
+    'gpf_create': (C.c_int, [C.POINTER(GpfConfig), _VPP]),
+    'gpf_destroy': (C.c_int, [C.c_void_p]),
+    'gpf_set_stream': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'gpf_last_error': (C.c_char_p, []),
+    'gpf_device_count': (C.c_int, []),
+    'gpf_upload': (C.c_int, [C.c_void_p, C.c_int, _DP, C.c_size_t]),
+    'gpf_download': (C.c_int, [C.c_void_p, C.c_int, _DP, C.c_size_t]),
+    'gpf_update_closures': (C.c_int, [C.c_void_p]),
+    'gpf_pre_run': (C.c_int, [C.c_void_p]),
+    'gpf_step': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(GpfScalars), C.c_int64, C.POINTER(C.c_int64)]),
+    'gpf_step_unfused': (C.c_int, [C.c_void_p]),
+    'gpf_scalars': (C.c_int, [C.c_void_p, C.POINTER(GpfScalars)]),
+    'gpf_set_ekin_old': (C.c_int, [C.c_void_p, C.c_double]),
+    'gpf_set_dt': (C.c_int, [C.c_void_p, C.c_double]),
+    'gpf_halo_buffers': (C.c_int, [C.c_void_p, _VPP, _VPP, _VPP, _VPP, C.POINTER(C.c_size_t)]),
+    'gpf_step_local': (C.c_int, [C.c_void_p, C.c_int, _VPP]),
+    'gpf_step_commit': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    'gpf_state': (C.c_int, [C.c_void_p, C.POINTER(GpfScalars)]),
+    'gpf_set_seam_topo': (C.c_int, [C.c_void_p, C.c_int, _DP, C.c_size_t]),
+    'gpf_predictor_corrector': (C.c_int, [C.c_int, C.c_int, _DP, _DP, _DP, C.c_int, _DP, _DP]),
+    'gpf_source': (C.c_int, [C.c_int, C.c_int, _DP, _DP, _DP, _DP, _DP, _DP]),
+}
+
+_lib = None
+
+
+class GapflowHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgapflow_hip.so once; raises if it has not been built (python -m gapflow_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GapflowHipError(
+                f"{LIB_PATH} not found: build it with `python -m gapflow_amd.build` (needs hipcc). "
+                "gapflow_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        raise GapflowHipError(f"libgapflow_hip error {code}: {load().gpf_last_error().decode()}")
+
+
+def require_device():
+    lib = load()
+    if lib.gpf_device_count() < 1:
+        raise GapflowHipError("no HIP device visible: gapflow_amd runs its hot path on an MI355X only "
+                              "(there is no CPU fallback)")
+    return lib
+
+
+def as_dp(a):
+    return a.ctypes.data_as(_DP)
+
+
+def f64c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)

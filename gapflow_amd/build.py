@@ -1,0 +1,50 @@
+"""Builds libgapflow_hip.so (gfx950 only) in-tree with hipcc.
+
+    python -m gapflow_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels to the
+GPU box with the working tree.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+LIB = os.path.join(LIBDIR, 'libgapflow_hip.so')
+SOURCES = ['api.hip']
+DEPS = ['api.hip', 'step_kernel.hip', 'aux_kernels.hip', 'gp_kernels.hip', 'closures.hpp', 'device_types.hpp',
+        os.path.join('..', '..', 'include', 'gapflow_hip.h')]
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-value',
+         '-ffp-contract=fast']
+LIBS = ['-L/opt/rocm/lib', '-lrocsolver', '-lrocblas', '-Wl,-rpath,/opt/rocm/lib']
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.exists(os.path.join(CSRC, d)) and os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build_library(force=False, verbose=False):
+    """Compile csrc/*.hip into lib/libgapflow_hip.so; returns the library path."""
+    if not force and not is_stale():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [HIPCC] + FLAGS + ['-Rpass-analysis=kernel-resource-usage', '-o', LIB] + SOURCES + LIBS
+    res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    with open(os.path.join(LIBDIR, 'resource_usage.txt'), 'w') as f:
+        f.write(res.stderr)
+    if res.returncode != 0:
+        errs = [ln for ln in res.stderr.splitlines() if 'remark:' not in ln]
+        raise RuntimeError('hipcc failed:\n' + '\n'.join(errs[-60:]))
+    if verbose:
+        print('built', LIB)
+    return LIB
+
+
+if __name__ == '__main__':
+    build_library(force='--force' in sys.argv, verbose=True)

@@ -1,0 +1,748 @@
+// C ABI of libgapflow_hip.so (see include/gapflow_hip.h for the contract of every entry point).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gapflow_hip.h"
+#include "step_kernel.hip"
+#include "aux_kernels.hip"
+
+using namespace gpf;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(GPF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
+    } while (0)
+
+#define GPF_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        int r_ = (expr);                                                                                \
+        if (r_ != GPF_OK) return r_;                                                                    \
+    } while (0)
+
+static_assert(sizeof(LogEntry) == sizeof(gpf_scalars_t), "LogEntry must mirror gpf_scalars_t");
+
+struct gpf_handle {
+    gpf_config cfg;
+    Layout L;
+    Edges E;
+    Phys P;
+    hipStream_t stream = nullptr;
+    // device state
+    double* q[2] = {nullptr, nullptr};      // ping-pong, 3 planes each
+    double* topo = nullptr;                 // 3 planes
+    double* Ls = nullptr;                   // 1 plane (allocated on first non-zero upload)
+    double* g1 = nullptr;                   // g1x [3][pitch] followed by g1y [3][Nx+2]
+    double* seam = nullptr;                 // [2 edges][2 rows][4: h,hx,hy,Ls][pitch]
+    bool has_seam[2] = {false, false};
+    double* halo = nullptr;                 // send_lo, send_hi, recv_lo, recv_hi: each [3][pitch]; then the 8-double slab record
+    StepState* st = nullptr;
+    Partial* partials = nullptr;
+    int npartials = 0, nstrips = 0, nchunks = 0, rows_per_chunk = 0;
+    ScalarPartial* spart = nullptr;         // k_scalars block records (+ 4 totals at the end)
+    int nspart = 0;
+    LogEntry* log = nullptr;
+    long long log_cap = 0;
+    double* stage = nullptr;                // contiguous staging for upload/download
+    size_t stage_doubles = 0;
+    // unfused pipeline scratch (lazy)
+    double* fields = nullptr;               // p(1) tau(3) lower(6) upper(6)
+    double* work = nullptr;                 // fx(3) fy(3) src(3)
+    bool has_q = false, has_topo = false, pre_run_done = false;
+    long long host_step = 0;                // step count at the last sync
+};
+
+// ---------------------------------------------------------------------------------------------
+static void make_phys(const gpf_config& c, Phys& P) {
+    std::memset(&P, 0, sizeof(P));
+    P.U = c.U; P.V = c.V; P.eta = c.eta; P.zeta = c.zeta;
+    P.inv_dx = 1.0 / c.dx; P.inv_dy = 1.0 / c.dy;
+    P.eos = c.eos; P.piezo = c.piezo;
+    const double* e = c.eos_par;
+    switch (c.eos) {
+    case GPF_EOS_DH:     // rho0, P0, C1, C2
+        P.e[0] = e[0]; P.e[1] = e[1]; P.e[2] = e[2]; P.e[3] = e[3];
+        P.e[4] = 0.99 * e[3] * e[0]; P.e[5] = 1.0 / e[0]; P.e[6] = e[2] * e[0] * (e[3] - 1.0);
+        break;
+    case GPF_EOS_PL:     // rho0, P0, alpha
+        P.e[0] = e[0]; P.e[1] = e[1]; P.e[2] = e[2]; P.e[3] = 1.0 / (1.0 - 0.5 * e[2]);
+        break;
+    case GPF_EOS_VDW:    // M, T, a, b   (pressure.py:168-173)
+        P.e[0] = 1000.0 / e[0]; P.e[1] = 8.31446261815324 * e[1]; P.e[2] = e[2] / 10.0; P.e[3] = e[3] / 1000.0;
+        break;
+    case GPF_EOS_MT:     // rho0, P0, K, n
+    case GPF_EOS_CUBIC:  // a, b, c, d
+        for (int i = 0; i < 4; ++i) P.e[i] = e[i];
+        break;
+    case GPF_EOS_BWR: {  // T, gamma; x1..x32 of Johnson, Zollweg & Gubbins (1993), pressure.py:255-272
+        static const double x[32] = {
+            0.8623085097507421, 2.976218765822098, -8.402230115796038, 0.1054136629203555, -0.8564583828174598,
+            1.582759470107601, 0.7639421948305453, 1.753173414312048, 2.798291772190376e+03, -4.8394220260857657e-02,
+            0.9963265197721935, -3.698000291272493e+01, 2.084012299434647e+01, 8.305402124717285e+01,
+            -9.574799715203068e+02, -1.477746229234994e+02, 6.398607852471505e+01, 1.603993673294834e+01,
+            6.805916615864377e+01, -2.791293578795945e+03, -6.245128304568454, -8.116836104958410e+03,
+            1.488735559561229e+01, -1.059346754655084e+04, -1.131607632802822e+02, -8.867771540418822e+03,
+            -3.986982844450543e+01, -4.689270299917261e+03, 2.593535277438717e+02, -2.694523589434903e+03,
+            -7.218487631550215e+02, 1.721802063863269e+02};
+        const double T = e[0], T2 = T * T, T3 = T2 * T, T4 = T2 * T2;
+        P.e[0] = e[1];
+        P.x[0] = T;
+        P.x[1] = x[0] * T + x[1] * std::sqrt(T) + x[2] + x[3] / T + x[4] / T2;
+        P.x[2] = x[5] * T + x[6] + x[7] / T + x[8] / T2;
+        P.x[3] = x[9] * T + x[10] + x[11] / T;
+        P.x[4] = x[12];
+        P.x[5] = x[13] / T + x[14] / T2;
+        P.x[6] = x[15] / T;
+        P.x[7] = x[16] / T + x[17] / T2;
+        P.x[8] = x[18] / T2;
+        P.x[9] = x[19] / T2 + x[20] / T3;
+        P.x[10] = x[21] / T2 + x[22] / T4;
+        P.x[11] = x[23] / T2 + x[24] / T3;
+        P.x[12] = x[25] / T2 + x[26] / T4;
+        P.x[13] = x[27] / T2 + x[28] / T3;
+        P.x[14] = x[29] / T2 + x[30] / T3 + x[31] / T4;
+        break;
+    }
+    case GPF_EOS_BAYADA: {   // rho_l, rho_v, c_l, c_v (pressure.py:303-304)
+        const double rl = e[0], rv = e[1], cl2 = e[2] * e[2], cv2 = e[3] * e[3];
+        const double N = rv * cv2 * rl * cl2 * (rv - rl) / (rv * rv * cv2 - rl * rl * cl2);
+        const double Pcav = rv * cv2 - N * std::log(rv * rv * cv2 / (rl * rl * cl2));
+        P.e[0] = rl; P.e[1] = rv; P.e[2] = cl2; P.e[3] = cv2; P.e[4] = N; P.e[5] = Pcav; P.e[6] = 1.0 / (rv - rl);
+        break;
+    }
+    }
+    const double* z = c.piezo_par;
+    switch (c.piezo) {
+    case GPF_PIEZO_BARUS: P.pz[0] = z[0]; break;
+    case GPF_PIEZO_ROELANDS: P.pz[0] = z[0]; P.pz[1] = z[1]; P.pz[2] = z[2]; P.pz[3] = std::log(c.eta / z[0]); break;
+    case GPF_PIEZO_DUKLER:
+    case GPF_PIEZO_MCADAMS: P.pz[0] = z[0]; P.pz[1] = z[1]; P.pz[2] = z[2]; break;
+    }
+}
+
+static int blocks_for(long long n, int bs = 256, int cap = 4096) {
+    long long b = (n + bs - 1) / bs;
+    return (int)std::max<long long>(1, std::min<long long>(b, cap));
+}
+
+#define EOS_DISPATCH(eos, CALL)                                                                         \
+    switch (eos) {                                                                                      \
+    case GPF_EOS_DH: { constexpr int EOS_ = EOS_DH; CALL; } break;                                     \
+    case GPF_EOS_PL: { constexpr int EOS_ = EOS_PL; CALL; } break;                                     \
+    case GPF_EOS_VDW: { constexpr int EOS_ = EOS_VDW; CALL; } break;                                   \
+    case GPF_EOS_MT: { constexpr int EOS_ = EOS_MT; CALL; } break;                                     \
+    case GPF_EOS_CUBIC: { constexpr int EOS_ = EOS_CUBIC; CALL; } break;                               \
+    case GPF_EOS_BWR: { constexpr int EOS_ = EOS_BWR; CALL; } break;                                   \
+    default: { constexpr int EOS_ = EOS_BAYADA; CALL; } break;                                         \
+    }
+
+// ---------------------------------------------------------------------------------------------
+extern "C" const char* gpf_last_error(void) { return g_err.c_str(); }
+
+extern "C" int gpf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int ensure_stage(gpf_handle* h, size_t doubles) {
+    if (h->stage_doubles >= doubles) return GPF_OK;
+    if (h->stage) HIP_TRY(hipFree(h->stage));
+    h->stage = nullptr; h->stage_doubles = 0;
+    HIP_TRY(hipMalloc(&h->stage, doubles * sizeof(double)));
+    h->stage_doubles = doubles;
+    return GPF_OK;
+}
+
+extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
+    if (!cfg || !out) return fail(GPF_ERR_INVALID, "gpf_create: null argument");
+    if (cfg->Nx < 1 || cfg->Ny < 1) return fail(GPF_ERR_INVALID, "gpf_create: Nx, Ny must be >= 1");
+    if (!(cfg->dx > 0) || !(cfg->dy > 0)) return fail(GPF_ERR_INVALID, "gpf_create: dx, dy must be > 0");
+    if (cfg->eos < GPF_EOS_DH || cfg->eos > GPF_EOS_BAYADA) return fail(GPF_ERR_INVALID, "gpf_create: unknown EOS id");
+    for (int e = 0; e < 4; ++e) {
+        int np = 0;
+        for (int c = 0; c < 3; ++c) {
+            int r = cfg->bc_rule[e][c];
+            if (r < 0 || r > 2) return fail(GPF_ERR_INVALID, "gpf_create: bad ghost rule");
+            np += (r == GPF_BC_PERIODIC);
+        }
+        if (np != 0 && np != 3)
+            return fail(GPF_ERR_INVALID, "gpf_create: an edge must be periodic for all components or for none "
+                                         "(problem.py:682-707 applies the periodic copy only when all three are 'P')");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(GPF_ERR_NO_DEVICE, "gpf_create: no HIP device visible (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(GPF_ERR_INVALID, "gpf_create: device ordinal out of range");
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    gpf_handle* h = new gpf_handle();
+    h->cfg = *cfg;
+    Layout& L = h->L;
+    L.Nx = cfg->Nx; L.Ny = cfg->Ny; L.off = 15;
+    L.pitch = ((cfg->Ny + 2 + L.off + 15) / 16) * 16;
+    L.plane = (long long)(cfg->Nx + 2) * L.pitch;
+    for (int e = 0; e < 4; ++e) {
+        for (int c = 0; c < 3; ++c) h->E.rule[e][c] = cfg->bc_rule[e][c];
+        h->E.value[e] = cfg->bc_value[e];
+    }
+    h->E.halo[0] = cfg->halo_lo; h->E.halo[1] = cfg->halo_hi;
+    make_phys(*cfg, h->P);
+
+    // strips / chunks of the fused step
+    h->nstrips = (L.Ny + STRIP - 1) / STRIP;
+    int rows = 0;
+    if (const char* s = std::getenv("GPF_ROWS_PER_CHUNK")) rows = std::atoi(s);
+    if (rows <= 0) {
+        int want_chunks = std::max(1, (4096 + h->nstrips - 1) / h->nstrips);
+        want_chunks = std::min(want_chunks, std::max(1, L.Nx / 16));
+        rows = (L.Nx + want_chunks - 1) / want_chunks;
+    }
+    h->rows_per_chunk = std::max(1, std::min(rows, L.Nx));
+    h->nchunks = (L.Nx + h->rows_per_chunk - 1) / h->rows_per_chunk;
+    h->npartials = h->nstrips * h->nchunks;
+
+    const size_t plane_b = (size_t)L.plane * sizeof(double);
+    auto cleanup = [&](int code) { gpf_destroy(h); return code; };
+#define HIP_TRY_C(expr)                                                                                 \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return cleanup(fail(GPF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)));      \
+    } while (0)
+    for (int b = 0; b < 2; ++b) {
+        HIP_TRY_C(hipMalloc(&h->q[b], 3 * plane_b));
+        HIP_TRY_C(hipMemset(h->q[b], 0, 3 * plane_b));
+    }
+    HIP_TRY_C(hipMalloc(&h->topo, 3 * plane_b));
+    HIP_TRY_C(hipMemset(h->topo, 0, 3 * plane_b));
+    const size_t g1n = (size_t)3 * L.pitch + (size_t)3 * (L.Nx + 2);
+    HIP_TRY_C(hipMalloc(&h->g1, g1n * sizeof(double)));
+    HIP_TRY_C(hipMemset(h->g1, 0, g1n * sizeof(double)));
+    HIP_TRY_C(hipMalloc(&h->st, sizeof(StepState)));
+    HIP_TRY_C(hipMemset(h->st, 0, sizeof(StepState)));
+    HIP_TRY_C(hipMalloc(&h->partials, (size_t)h->npartials * sizeof(Partial)));
+    HIP_TRY_C(hipMemset(h->partials, 0, (size_t)h->npartials * sizeof(Partial)));
+    h->nspart = 1024;
+    HIP_TRY_C(hipMalloc(&h->spart, (size_t)(h->nspart + 8) * sizeof(ScalarPartial)));
+    HIP_TRY_C(hipMemset(h->spart, 0, (size_t)(h->nspart + 8) * sizeof(ScalarPartial)));
+    h->log_cap = 4096;
+    HIP_TRY_C(hipMalloc(&h->log, (size_t)h->log_cap * sizeof(LogEntry)));
+#undef HIP_TRY_C
+    *out = h;
+    return GPF_OK;
+}
+
+extern "C" int gpf_destroy(gpf_handle* h) {
+    if (!h) return GPF_OK;
+    hipSetDevice(h->cfg.device);
+    void* ptrs[] = {h->q[0], h->q[1], h->topo, h->Ls, h->g1, h->seam, h->halo, h->st, h->partials, h->spart,
+                    h->log, h->stage, h->fields, h->work};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    delete h;
+    return GPF_OK;
+}
+
+extern "C" int gpf_set_stream(gpf_handle* h, void* s) {
+    if (!h) return fail(GPF_ERR_INVALID, "null handle");
+    h->stream = (hipStream_t)s;
+    return GPF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int field_ncomp(int field) {
+    switch (field) {
+    case GPF_FIELD_Q: return 3;
+    case GPF_FIELD_TOPO: return 3;
+    case GPF_FIELD_EXTRA: return 1;
+    case GPF_FIELD_PRESSURE: return 1;
+    case GPF_FIELD_TAU_AVG: return 3;
+    case GPF_FIELD_WALL_LOWER: return 6;
+    case GPF_FIELD_WALL_UPPER: return 6;
+    }
+    return 0;
+}
+
+static int current_parity(gpf_handle* h, int* par) {
+    StepState s;
+    HIP_TRY(hipMemcpyAsync(&s, h->st, sizeof(s), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *par = s.parity;
+    return GPF_OK;
+}
+
+static int ensure_fields(gpf_handle* h) {
+    if (h->fields) return GPF_OK;
+    HIP_TRY(hipMalloc(&h->fields, (size_t)16 * h->L.plane * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(h->fields, 0, (size_t)16 * h->L.plane * sizeof(double), h->stream));
+    return GPF_OK;
+}
+
+extern "C" int gpf_upload(gpf_handle* h, int field, const double* host, size_t count) {
+    if (!h || !host) return fail(GPF_ERR_INVALID, "gpf_upload: null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const Layout& L = h->L;
+    const int nc = field_ncomp(field);
+    if (field != GPF_FIELD_Q && field != GPF_FIELD_TOPO && field != GPF_FIELD_EXTRA)
+        return fail(GPF_ERR_INVALID, "gpf_upload: only q, topography and the extra field are inputs");
+    const size_t ncell = (size_t)(L.Nx + 2) * (L.Ny + 2);
+    if (count != ncell * nc) return fail(GPF_ERR_INVALID, "gpf_upload: count does not match ncomp*(Nx+2)*(Ny+2)");
+    double* dst = nullptr;
+    if (field == GPF_FIELD_Q) {
+        int par = 0;
+        GPF_TRY(current_parity(h, &par));
+        dst = h->q[par];
+    } else if (field == GPF_FIELD_TOPO) {
+        dst = h->topo;
+    } else {
+        bool nz = false;
+        for (size_t i = 0; i < count && !nz; ++i) nz = host[i] != 0.0;
+        if (!nz && !h->Ls) return GPF_OK;      // Ls == 0 everywhere: the HAS_LS=false kernels apply
+        if (!h->Ls) HIP_TRY(hipMalloc(&h->Ls, (size_t)L.plane * sizeof(double)));
+        HIP_TRY(hipMemsetAsync(h->Ls, 0, (size_t)L.plane * sizeof(double), h->stream));
+        dst = h->Ls;
+    }
+    GPF_TRY(ensure_stage(h, count));
+    HIP_TRY(hipMemcpyAsync(h->stage, host, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_pack, dim3(blocks_for((long long)count)), dim3(256), 0, h->stream, h->stage, dst, L, nc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (field == GPF_FIELD_Q) h->has_q = true;
+    if (field == GPF_FIELD_TOPO) h->has_topo = true;
+    return GPF_OK;
+}
+
+extern "C" int gpf_download(gpf_handle* h, int field, double* host, size_t count) {
+    if (!h || !host) return fail(GPF_ERR_INVALID, "gpf_download: null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const Layout& L = h->L;
+    const int nc = field_ncomp(field);
+    if (nc == 0) return fail(GPF_ERR_INVALID, "gpf_download: unknown field id");
+    const size_t ncell = (size_t)(L.Nx + 2) * (L.Ny + 2);
+    if (count != ncell * nc) return fail(GPF_ERR_INVALID, "gpf_download: count does not match ncomp*(Nx+2)*(Ny+2)");
+    const double* src = nullptr;
+    switch (field) {
+    case GPF_FIELD_Q: {
+        int par = 0;
+        GPF_TRY(current_parity(h, &par));
+        src = h->q[par];
+        break;
+    }
+    case GPF_FIELD_TOPO: src = h->topo; break;
+    case GPF_FIELD_EXTRA:
+        if (!h->Ls) { std::memset(host, 0, count * sizeof(double)); return GPF_OK; }
+        src = h->Ls; break;
+    default:
+        if (!h->fields) return fail(GPF_ERR_STATE, "gpf_download: derived fields requested before gpf_update_closures");
+        src = h->fields + (field == GPF_FIELD_PRESSURE ? 0 : field == GPF_FIELD_TAU_AVG ? 1 : field == GPF_FIELD_WALL_LOWER ? 4 : 10) * L.plane;
+    }
+    GPF_TRY(ensure_stage(h, count));
+    hipLaunchKernelGGL(k_unpack, dim3(blocks_for((long long)count)), dim3(256), 0, h->stream, src, h->stage, L, nc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host, h->stage, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return GPF_OK;
+}
+
+static FieldPtrs field_ptrs(gpf_handle* h) {
+    FieldPtrs F;
+    F.p = h->fields; F.tau = h->fields + h->L.plane; F.lower = h->fields + 4 * h->L.plane; F.upper = h->fields + 10 * h->L.plane;
+    return F;
+}
+
+static int launch_fields(gpf_handle* h, const double* q) {
+    GPF_TRY(ensure_fields(h));
+    const Layout& L = h->L;
+    const long long n = (long long)(L.Nx + 2) * (L.Ny + 2);
+    FieldPtrs F = field_ptrs(h);
+    EOS_DISPATCH(h->cfg.eos, {
+        if (h->Ls) hipLaunchKernelGGL((k_fields<EOS_, true>), dim3(blocks_for(n)), dim3(256), 0, h->stream, q, h->topo, h->Ls, F, L, h->P);
+        else hipLaunchKernelGGL((k_fields<EOS_, false>), dim3(blocks_for(n)), dim3(256), 0, h->stream, q, h->topo, (const double*)nullptr, F, L, h->P);
+    });
+    HIP_TRY(hipGetLastError());
+    return GPF_OK;
+}
+
+extern "C" int gpf_update_closures(gpf_handle* h) {
+    if (!h) return fail(GPF_ERR_INVALID, "null handle");
+    if (!h->has_q || !h->has_topo) return fail(GPF_ERR_STATE, "gpf_update_closures: upload q and topography first");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    int par = 0;
+    GPF_TRY(current_parity(h, &par));
+    GPF_TRY(launch_fields(h, h->q[par]));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return GPF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scalars
+// ---------------------------------------------------------------------------------------------
+static int launch_scalars(gpf_handle* h, const double* q, ScalarPartial* total) {
+    const Layout& L = h->L;
+    const int row0 = h->E.halo[0] ? 1 : 0, row1 = h->E.halo[1] ? L.Nx : L.Nx + 1;
+    const long long n = (long long)(row1 - row0 + 1) * (L.Ny + 2);
+    const int nb = blocks_for(n, 256, h->nspart);
+    EOS_DISPATCH(h->cfg.eos, {
+        hipLaunchKernelGGL((k_scalars<EOS_>), dim3(nb), dim3(256), 0, h->stream, q, h->topo, L, h->P, row0, row1, h->spart);
+    });
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_scalars_final, dim3(1), dim3(256), 0, h->stream, h->spart, nb, total);
+    HIP_TRY(hipGetLastError());
+    return GPF_OK;
+}
+
+static void fill_scalars(const StepState& s, const ScalarPartial* sp, double dxdy, gpf_scalars_t* out) {
+    out->step = s.step; out->simtime = s.simtime; out->dt = s.dt;
+    out->ekin = sp ? sp->ekin : s.ekin; out->ekin_old = s.ekin_old; out->residual = s.residual;
+    out->v_max = std::sqrt(sp ? sp->v2 : s.vmax2); out->v_sound = std::sqrt(sp ? sp->c2 : s.c2max);
+    out->mass = sp ? sp->mass * dxdy : 0.0;
+    out->invalid = s.invalid; out->converged = s.converged;
+}
+
+extern "C" int gpf_scalars(gpf_handle* h, gpf_scalars_t* out) {
+    if (!h || !out) return fail(GPF_ERR_INVALID, "gpf_scalars: null argument");
+    if (!h->has_q || !h->has_topo) return fail(GPF_ERR_STATE, "gpf_scalars: upload q and topography first");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    int par = 0;
+    GPF_TRY(current_parity(h, &par));
+    ScalarPartial* tot = h->spart + h->nspart;
+    GPF_TRY(launch_scalars(h, h->q[par], tot));
+    ScalarPartial sp; StepState s;
+    HIP_TRY(hipMemcpyAsync(&sp, tot, sizeof(sp), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(&s, h->st, sizeof(s), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    fill_scalars(s, &sp, h->cfg.dx * h->cfg.dy, out);
+    return GPF_OK;
+}
+
+static int write_state(gpf_handle* h, const StepState& s) {
+    HIP_TRY(hipMemcpyAsync(h->st, &s, sizeof(s), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return GPF_OK;
+}
+static int read_state(gpf_handle* h, StepState& s) {
+    HIP_TRY(hipMemcpyAsync(&s, h->st, sizeof(s), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return GPF_OK;
+}
+
+extern "C" int gpf_set_ekin_old(gpf_handle* h, double v) {
+    if (!h) return fail(GPF_ERR_INVALID, "null handle");
+    StepState s;
+    GPF_TRY(read_state(h, s));
+    s.ekin_old = v;
+    return write_state(h, s);
+}
+
+extern "C" int gpf_set_dt(gpf_handle* h, double dt) {
+    if (!h) return fail(GPF_ERR_INVALID, "null handle");
+    StepState s;
+    GPF_TRY(read_state(h, s));
+    s.dt = dt;
+    return write_state(h, s);
+}
+
+// Problem._initialize's Ekin_old (problem.py:670) + _pre_run (problem.py:412-443)
+extern "C" int gpf_pre_run(gpf_handle* h) {
+    if (!h) return fail(GPF_ERR_INVALID, "null handle");
+    if (!h->has_q || !h->has_topo) return fail(GPF_ERR_STATE, "gpf_pre_run: upload q and topography first");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    gpf_scalars_t sc;
+    GPF_TRY(gpf_scalars(h, &sc));
+    StepState s;
+    GPF_TRY(read_state(h, s));
+    const gpf_config& c = h->cfg;
+    s.hmin = std::min(c.dx, c.dy);
+    s.tol = c.tol; s.CFL = c.CFL; s.adaptive = c.adaptive; s.mc_order = c.mc_order; s.max_it = c.max_it;
+    s.step = 0; s.simtime = 0.0; s.residual = 1.0;
+    s.rbuf[0] = 1.0; s.rcount = 1; s.rhead = 0;
+    s.converged = (1.0 < c.tol) ? 1 : 0;
+    s.invalid = 0;
+    if (!h->pre_run_done) s.ekin_old = sc.ekin;     // otherwise keep a user-set kinetic_energy_old
+    s.ekin = sc.ekin;
+    s.vmax2 = sc.v_max * sc.v_max; s.c2max = sc.v_sound * sc.v_sound;
+    const double dt_crit = s.hmin / (sc.v_max + sc.v_sound);
+    s.dt = c.adaptive ? c.CFL * dt_crit : c.dt_fixed;
+    GPF_TRY(write_state(h, s));
+    h->pre_run_done = true;
+    h->host_step = 0;
+    return GPF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the fused step
+// ---------------------------------------------------------------------------------------------
+static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, double* slab_out) {
+    const Layout& L = h->L;
+    StepArgs a;
+    a.qa = h->q[0]; a.qb = h->q[1]; a.topo = h->topo; a.Ls = h->Ls;
+    a.g1x = h->g1; a.g1y = h->g1 + 3 * L.pitch;
+    a.st = h->st; a.partials = h->partials; a.L = L; a.E = h->E;
+    a.rows_per_chunk = h->rows_per_chunk; a.nstrips = h->nstrips; a.honor_stop = honor_stop;
+    GhostArgs g;
+    g.qa = h->q[0]; g.qb = h->q[1]; g.topo = h->topo; g.Ls = h->Ls;
+    for (int e = 0; e < 2; ++e) {
+        g.seam[e] = nullptr;
+        if (h->E.halo[e] == 2) {
+            if (!h->has_seam[e]) return fail(GPF_ERR_STATE, "periodic slab seam: call gpf_set_seam_topo for this edge first");
+            g.seam[e] = h->seam + (size_t)e * 8 * L.pitch;
+        }
+    }
+    g.g1x = h->g1; g.g1y = h->g1 + 3 * L.pitch; g.st = h->st; g.L = L; g.E = h->E; g.honor_stop = honor_stop;
+    FinishArgs f;
+    f.qa = h->q[0]; f.qb = h->q[1]; f.partials = h->partials; f.npartials = h->npartials; f.st = h->st;
+    f.L = L; f.E = h->E;
+    f.log = h->log; f.log_base = log_base; f.log_cap = h->log_cap; f.out = slab_out; f.honor_stop = honor_stop;
+
+    const int gmax = std::max(L.Nx, L.Ny);
+    const dim3 ggrid((gmax + 255) / 256, 2), sgrid((h->nstrips + 3) / 4, h->nchunks);
+    EOS_DISPATCH(h->cfg.eos, {
+        if (h->Ls) {
+            hipLaunchKernelGGL((k_ghost_stage1<EOS_, true>), ggrid, dim3(256), 0, h->stream, g, h->P);
+            hipLaunchKernelGGL((k_step<EOS_, true>), sgrid, dim3(256), 0, h->stream, a, h->P);
+        } else {
+            hipLaunchKernelGGL((k_ghost_stage1<EOS_, false>), ggrid, dim3(256), 0, h->stream, g, h->P);
+            hipLaunchKernelGGL((k_step<EOS_, false>), sgrid, dim3(256), 0, h->stream, a, h->P);
+        }
+        hipLaunchKernelGGL((k_finish<EOS_>), dim3(1), dim3(1024), 0, h->stream, f, h->P);
+    });
+    HIP_TRY(hipGetLastError());
+    return GPF_OK;
+}
+
+extern "C" int gpf_step(gpf_handle* h, int64_t n, int honor_stop, gpf_scalars_t* log, int64_t log_capacity,
+                        int64_t* n_executed) {
+    if (!h) return fail(GPF_ERR_INVALID, "null handle");
+    if (!h->pre_run_done) return fail(GPF_ERR_STATE, "gpf_step: call gpf_pre_run first (Problem._pre_run, problem.py:412)");
+    if (h->E.halo[0] || h->E.halo[1]) return fail(GPF_ERR_STATE, "gpf_step: this handle is a slab; use gpf_step_local / gpf_step_commit");
+    if (n < 0) return fail(GPF_ERR_INVALID, "gpf_step: n < 0");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    int64_t done = 0, logged = 0;
+    while (done < n) {
+        const int64_t batch = std::min<int64_t>(n - done, h->log_cap);
+        const long long base = h->host_step;
+        for (int64_t i = 0; i < batch; ++i) GPF_TRY(enqueue_step(h, honor_stop, base, nullptr));
+        StepState s;
+        GPF_TRY(read_state(h, s));
+        const long long ran = s.step - base;
+        const long long entries = ran + ((s.invalid && ran < batch) ? 1 : 0);
+        if (log && entries > 0) {
+            const long long take = std::min<long long>(entries, log_capacity - logged);
+            if (take > 0) {
+                HIP_TRY(hipMemcpy(log + logged, h->log, (size_t)take * sizeof(LogEntry), hipMemcpyDeviceToHost));
+                logged += take;
+            }
+        }
+        h->host_step = s.step;
+        done += batch;
+        if (ran < batch) break;     // stopped on the device (converged / max_it / invalid)
+    }
+    if (n_executed) *n_executed = h->host_step;
+    return GPF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the unfused, reference-ordered step (problem.py:509-586 line by line)
+// ---------------------------------------------------------------------------------------------
+extern "C" int gpf_step_unfused(gpf_handle* h) {
+    if (!h) return fail(GPF_ERR_INVALID, "null handle");
+    if (!h->pre_run_done) return fail(GPF_ERR_STATE, "gpf_step_unfused: call gpf_pre_run first");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const Layout& L = h->L;
+    GPF_TRY(ensure_fields(h));
+    if (!h->work) HIP_TRY(hipMalloc(&h->work, (size_t)9 * L.plane * sizeof(double)));
+    StepState s;
+    GPF_TRY(read_state(h, s));
+    if (s.invalid) return GPF_OK;
+    const double* q0 = h->q[s.parity];
+    double* q = h->q[s.parity ^ 1];
+    const long long n = (long long)(L.Nx + 2) * (L.Ny + 2);
+    const int nb = blocks_for(n);
+    double *fx = h->work, *fy = h->work + 3 * L.plane, *src = h->work + 6 * L.plane;
+    FieldPtrs F = field_ptrs(h);
+    hipLaunchKernelGGL(k_copy3, dim3(blocks_for(3 * L.plane)), dim3(256), 0, h->stream, q0, q, 3 * L.plane);
+    const int sw = s.mc_order == 0 ? ((s.step % 2 == 0) ? 1 : -1) : s.mc_order;
+    const int dirs[2] = {((sw + 1) / 2) ? 1 : -1, ((sw + 1) / 2) ? -1 : 1};
+    for (int i = 0; i < 2; ++i) {
+        GPF_TRY(launch_fields(h, q));
+        hipLaunchKernelGGL(k_fluxdiff, dim3(nb), dim3(256), 0, h->stream, q, F.p, F.tau, dirs[i], fx, fy, L);
+        hipLaunchKernelGGL(k_source, dim3(nb), dim3(256), 0, h->stream, q, h->topo, F.tau, F.lower, F.upper, src, L);
+        hipLaunchKernelGGL(k_axpy, dim3(nb), dim3(256), 0, h->stream, q, fx, fy, src, h->st, h->cfg.dx, h->cfg.dy, L);
+        hipLaunchKernelGGL(k_bc_x, dim3((L.Ny + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
+        hipLaunchKernelGGL(k_bc_y, dim3((L.Nx + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
+    }
+    hipLaunchKernelGGL(k_average, dim3(nb), dim3(256), 0, h->stream, q, q0, L);
+    ScalarPartial* pre = h->spart + h->nspart;
+    ScalarPartial* post = h->spart + h->nspart + 1;
+    GPF_TRY(launch_scalars(h, q, pre));                 // validity of the averaged field (problem.py:565)
+    hipLaunchKernelGGL(k_bc_x, dim3((L.Ny + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
+    hipLaunchKernelGGL(k_bc_y, dim3((L.Nx + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
+    GPF_TRY(launch_scalars(h, q, post));                // scalars after the ghost update (problem.py:576-578)
+    hipLaunchKernelGGL(k_commit_unfused, dim3(1), dim3(1), 0, h->stream, h->st, pre, post);
+    HIP_TRY(hipGetLastError());
+    GPF_TRY(read_state(h, s));
+    h->host_step = s.step;
+    return GPF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stateless operators (integrate.py)
+// ---------------------------------------------------------------------------------------------
+static Layout dense_layout(int nx, int ny) {
+    Layout L;
+    L.Nx = nx - 2; L.Ny = ny - 2; L.pitch = ny; L.off = 0; L.plane = (long long)nx * ny;
+    return L;
+}
+
+extern "C" int gpf_predictor_corrector(int nx, int ny, const double* q, const double* p, const double* tau,
+                                       int direction, double* flux_x, double* flux_y) {
+    if (!q || !p || !tau || !flux_x || !flux_y) return fail(GPF_ERR_INVALID, "gpf_predictor_corrector: null argument");
+    if (nx < 1 || ny < 1 || (direction != 1 && direction != -1))
+        return fail(GPF_ERR_INVALID, "gpf_predictor_corrector: nx, ny >= 1 and direction = +-1 required");
+    if (gpf_device_count() == 0) return fail(GPF_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    const Layout L = dense_layout(nx, ny);
+    const size_t n = (size_t)nx * ny;
+    double* d = nullptr;
+    HIP_TRY(hipMalloc(&d, 13 * n * sizeof(double)));
+    double *dq = d, *dp = d + 3 * n, *dt = d + 4 * n, *dfx = d + 7 * n, *dfy = d + 10 * n;
+    int rc = GPF_OK;
+    hipError_t e;
+    if ((e = hipMemcpy(dq, q, 3 * n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(dp, p, n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(dt, tau, 3 * n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) {
+        rc = fail(GPF_ERR_HIP, hipGetErrorString(e));
+    } else {
+        hipLaunchKernelGGL(k_fluxdiff, dim3(blocks_for((long long)n)), dim3(256), 0, 0, dq, dp, dt, direction, dfx, dfy, L);
+        if ((e = hipGetLastError()) != hipSuccess ||
+            (e = hipMemcpy(flux_x, dfx, 3 * n * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess ||
+            (e = hipMemcpy(flux_y, dfy, 3 * n * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess)
+            rc = fail(GPF_ERR_HIP, hipGetErrorString(e));
+    }
+    hipFree(d);
+    return rc;
+}
+
+extern "C" int gpf_source(int nx, int ny, const double* q, const double* hh, const double* stress, const double* lower,
+                          const double* upper, double* out) {
+    if (!q || !hh || !stress || !lower || !upper || !out) return fail(GPF_ERR_INVALID, "gpf_source: null argument");
+    if (nx < 1 || ny < 1) return fail(GPF_ERR_INVALID, "gpf_source: nx, ny >= 1 required");
+    if (gpf_device_count() == 0) return fail(GPF_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    const Layout L = dense_layout(nx, ny);
+    const size_t n = (size_t)nx * ny;
+    double* d = nullptr;
+    HIP_TRY(hipMalloc(&d, 24 * n * sizeof(double)));
+    double *dq = d, *dh = d + 3 * n, *ds = d + 6 * n, *dl = d + 9 * n, *du = d + 15 * n, *dout = d + 21 * n;
+    int rc = GPF_OK;
+    hipError_t e;
+    if ((e = hipMemcpy(dq, q, 3 * n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(dh, hh, 3 * n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(ds, stress, 3 * n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(dl, lower, 6 * n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(du, upper, 6 * n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) {
+        rc = fail(GPF_ERR_HIP, hipGetErrorString(e));
+    } else {
+        hipLaunchKernelGGL(k_source, dim3(blocks_for((long long)n)), dim3(256), 0, 0, dq, dh, ds, dl, du, dout, L);
+        if ((e = hipGetLastError()) != hipSuccess ||
+            (e = hipMemcpy(out, dout, 3 * n * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess)
+            rc = fail(GPF_ERR_HIP, hipGetErrorString(e));
+    }
+    hipFree(d);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// slab decomposition
+// ---------------------------------------------------------------------------------------------
+static int ensure_halo(gpf_handle* h) {
+    if (h->halo) return GPF_OK;
+    const size_t n = (size_t)12 * h->L.pitch + 8;
+    HIP_TRY(hipMalloc(&h->halo, n * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(h->halo, 0, n * sizeof(double), h->stream));
+    return GPF_OK;
+}
+
+extern "C" int gpf_halo_buffers(gpf_handle* h, void** send_lo, void** send_hi, void** recv_lo, void** recv_hi,
+                                size_t* count) {
+    if (!h || !send_lo || !send_hi || !recv_lo || !recv_hi || !count) return fail(GPF_ERR_INVALID, "gpf_halo_buffers: null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    GPF_TRY(ensure_halo(h));
+    const size_t m = (size_t)3 * h->L.pitch;
+    *send_lo = h->halo; *send_hi = h->halo + m; *recv_lo = h->halo + 2 * m; *recv_hi = h->halo + 3 * m;
+    *count = m;
+    return GPF_OK;
+}
+
+static HaloArgs halo_args(gpf_handle* h, int honor_stop) {
+    const size_t m = (size_t)3 * h->L.pitch;
+    HaloArgs a;
+    a.qa = h->q[0]; a.qb = h->q[1];
+    a.send_lo = h->halo; a.send_hi = h->halo + m; a.recv_lo = h->halo + 2 * m; a.recv_hi = h->halo + 3 * m;
+    a.st = h->st; a.L = h->L; a.E = h->E; a.honor_stop = honor_stop;
+    return a;
+}
+
+extern "C" int gpf_step_local(gpf_handle* h, int honor_stop, void** totals) {
+    if (!h || !totals) return fail(GPF_ERR_INVALID, "gpf_step_local: null argument");
+    if (!h->pre_run_done) return fail(GPF_ERR_STATE, "gpf_step_local: call gpf_pre_run first");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    GPF_TRY(ensure_halo(h));
+    double* rec = h->halo + (size_t)12 * h->L.pitch;
+    GPF_TRY(enqueue_step(h, honor_stop, h->host_step, rec));
+    hipLaunchKernelGGL(k_halo_pack, dim3((h->L.pitch + 255) / 256), dim3(256), 0, h->stream, halo_args(h, honor_stop));
+    HIP_TRY(hipGetLastError());
+    *totals = rec;
+    return GPF_OK;
+}
+
+extern "C" int gpf_step_commit(gpf_handle* h, int honor_stop, const void* gathered, int nranks) {
+    if (!h || !gathered || nranks < 1) return fail(GPF_ERR_INVALID, "gpf_step_commit: bad argument");
+    if (!h->halo) return fail(GPF_ERR_STATE, "gpf_step_commit without gpf_step_local");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_halo_unpack, dim3((h->L.pitch + 255) / 256), dim3(256), 0, h->stream, halo_args(h, honor_stop));
+    hipLaunchKernelGGL(k_commit_gathered, dim3(1), dim3(1), 0, h->stream, h->st, (const double*)gathered, nranks,
+                       h->log, (long long)h->host_step, (long long)h->log_cap, honor_stop);
+    HIP_TRY(hipGetLastError());
+    return GPF_OK;
+}
+
+extern "C" int gpf_state(gpf_handle* h, gpf_scalars_t* out) {
+    if (!h || !out) return fail(GPF_ERR_INVALID, "gpf_state: null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    StepState s;
+    GPF_TRY(read_state(h, s));
+    fill_scalars(s, nullptr, 0.0, out);
+    h->host_step = s.step;
+    return GPF_OK;
+}
+
+extern "C" int gpf_set_seam_topo(gpf_handle* h, int side, const double* host, size_t count) {
+    if (!h || !host || side < 0 || side > 1) return fail(GPF_ERR_INVALID, "gpf_set_seam_topo: bad argument");
+    const Layout& L = h->L;
+    if (count != (size_t)8 * (L.Ny + 2)) return fail(GPF_ERR_INVALID, "gpf_set_seam_topo: count must be 2*4*(Ny+2)");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (!h->seam) {
+        HIP_TRY(hipMalloc(&h->seam, (size_t)16 * L.pitch * sizeof(double)));
+        HIP_TRY(hipMemset(h->seam, 0, (size_t)16 * L.pitch * sizeof(double)));
+    }
+    std::vector<double> tmp((size_t)8 * L.pitch, 0.0);
+    for (int r = 0; r < 8; ++r)
+        for (int iy = 0; iy < L.Ny + 2; ++iy) tmp[(size_t)r * L.pitch + L.off + iy] = host[(size_t)r * (L.Ny + 2) + iy];
+    HIP_TRY(hipMemcpy(h->seam + (size_t)side * 8 * L.pitch, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->has_seam[side] = true;
+    return GPF_OK;
+}

@@ -1,0 +1,437 @@
+// Everything around the fused step: ghost-cell rules, per-step scalar reductions and the
+// device-side dt / residual update, the reference-ordered unfused stage pipeline, the
+// stateless integrate.py operators, and host<->device layout conversion.
+#include <hip/hip_runtime.h>
+#include "device_types.hpp"
+
+namespace gpf {
+
+// ---------------------------------------------------------------------------------------------
+// layout conversion: reference layout [c][ix][iy] (pitch Ny+2)  <->  padded planes
+// ---------------------------------------------------------------------------------------------
+__global__ void k_pack(const double* __restrict__ src, double* __restrict__ dst, Layout L, int ncomp) {
+    const long long ncell = (long long)(L.Nx + 2) * (L.Ny + 2);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < ncell * ncomp;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i / ncell);
+        const long long r = i - c * ncell;
+        const int ix = (int)(r / (L.Ny + 2)), iy = (int)(r - (long long)ix * (L.Ny + 2));
+        dst[c * L.plane + L.at(ix, iy)] = src[i];
+    }
+}
+
+__global__ void k_unpack(const double* __restrict__ src, double* __restrict__ dst, Layout L, int ncomp) {
+    const long long ncell = (long long)(L.Nx + 2) * (L.Ny + 2);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < ncell * ncomp;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i / ncell);
+        const long long r = i - c * ncell;
+        const int ix = (int)(r / (L.Ny + 2)), iy = (int)(r - (long long)ix * (L.Ny + 2));
+        dst[i] = src[c * L.plane + L.at(ix, iy)];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ghost-cell rules (problem.py:676-768), one value
+// ---------------------------------------------------------------------------------------------
+// x edge e in {0: ix=0, 1: ix=Nx+1}: returns the ghost value of component c in column iy
+__device__ __forceinline__ double ghost_x(const double* q, const Layout& L, const Edges& E, int e, int c, int iy) {
+    const int r = E.rule[e][c];
+    const int adj = e == 0 ? 1 : L.Nx;
+    const int src = (r == BC_P) ? (e == 0 ? L.Nx : 1) : adj;
+    const double v = q[c * L.plane + L.at(src, iy)];
+    return r == BC_D ? 2.0 * E.value[e] - v : v;
+}
+// y edge e in {2: iy=0, 3: iy=Ny+1}
+__device__ __forceinline__ double ghost_y(const double* q, const Layout& L, const Edges& E, int e, int c, int ix) {
+    const int r = E.rule[e][c];
+    const int adj = e == 2 ? 1 : L.Ny;
+    const int src = (r == BC_P) ? (e == 2 ? L.Ny : 1) : adj;
+    const double v = q[c * L.plane + L.at(ix, src)];
+    return r == BC_D ? 2.0 * E.value[e] - v : v;
+}
+
+// x edges for all columns (ghost columns included, as the reference does), then -- in a second
+// launch or after a barrier -- y edges for all rows: corners end up as rule_y(rule_x(.)).
+__global__ void k_bc_x(double* q, Layout L, Edges E) {
+    const int iy = blockIdx.x * blockDim.x + threadIdx.x;
+    if (iy > L.Ny + 1) return;
+    for (int e = 0; e < 2; ++e) {
+        if (E.halo[e]) continue;
+        const int ix = e == 0 ? 0 : L.Nx + 1;
+        double v[3];
+        for (int c = 0; c < 3; ++c) v[c] = ghost_x(q, L, E, e, c, iy);
+        for (int c = 0; c < 3; ++c) q[c * L.plane + L.at(ix, iy)] = v[c];
+    }
+}
+__global__ void k_bc_y(double* q, Layout L, Edges E) {
+    const int ix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ix > L.Nx + 1) return;
+    for (int e = 2; e < 4; ++e) {
+        const int iy = e == 2 ? 0 : L.Ny + 1;
+        double v[3];
+        for (int c = 0; c < 3; ++c) v[c] = ghost_y(q, L, E, e, c, ix);
+        for (int c = 0; c < 3; ++c) q[c * L.plane + L.at(ix, iy)] = v[c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// scalars
+// ---------------------------------------------------------------------------------------------
+struct Acc {
+    double ekin, v2, c2, mass;
+    int flags;
+    __device__ __forceinline__ void zero() { ekin = 0; v2 = 0; c2 = 0; mass = 0; flags = 0; }
+    template <int EOS>
+    __device__ __forceinline__ void cell(double r, double jx, double jy, double h, const Phys& P, double w = 1.0) {
+        const double v = (jx * jx + jy * jy) / r;
+        ekin += w * (v * 0.5);
+        v2 = nanmax(v2, v);
+        double c = eos_c2<EOS>(r, P);
+        c = (c < 0.0) ? __builtin_nan("") : c;
+        c2 = nanmax(c2, c);
+        mass += w * (r * h);
+        if (r != r || jx != jx || jy != jy) flags |= 1;
+        if (r < 0.0) flags |= 2;
+    }
+    __device__ __forceinline__ void merge(const Acc& o) {
+        ekin += o.ekin; v2 = nanmax(v2, o.v2); c2 = nanmax(c2, o.c2); mass += o.mass; flags |= o.flags;
+    }
+};
+
+__device__ __forceinline__ Acc wave_reduce(Acc a) {
+    for (int s = 32; s >= 1; s >>= 1) {
+        Acc o;
+        o.ekin = __shfl_down(a.ekin, s); o.v2 = __shfl_down(a.v2, s); o.c2 = __shfl_down(a.c2, s);
+        o.mass = __shfl_down(a.mass, s); o.flags = __shfl_down(a.flags, s);
+        a.merge(o);
+    }
+    return a;
+}
+
+// block reduction; result valid in thread 0.  smem: at least blockDim.x/64 entries.
+__device__ __forceinline__ Acc block_reduce(Acc a, Acc* smem) {
+    a = wave_reduce(a);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) smem[w] = a;
+    __syncthreads();
+    Acc r; r.zero();
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r.merge(smem[i]);
+    }
+    __syncthreads();
+    return r;
+}
+
+struct ScalarPartial { double ekin, v2, c2, mass, flags; };
+
+// Full-array scalars of an arbitrary state (Problem.mass / kinetic_energy / v_max / v_sound,
+// problem.py:334-352).  Rows [row0, row1] are summed: a slab leaves out halo rows it does not own.
+template <int EOS>
+__global__ __launch_bounds__(256) void k_scalars(const double* q, const double* topo, Layout L, Phys P, int row0,
+                                                 int row1, ScalarPartial* out) {
+    __shared__ Acc sm[4];
+    Acc a; a.zero();
+    const long long w = L.Ny + 2;
+    const long long n = (long long)(row1 - row0 + 1) * w;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int ix = row0 + (int)(i / w), iy = (int)(i % w);
+        const long long o = L.at(ix, iy);
+        a.cell<EOS>(q[o], q[o + L.plane], q[o + 2 * L.plane], topo[o], P);
+    }
+    a = block_reduce(a, sm);
+    if (threadIdx.x == 0) {
+        ScalarPartial p = {a.ekin, a.v2, a.c2, a.mass, (double)a.flags};
+        out[blockIdx.x] = p;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// commit: dt / residual / convergence bookkeeping (problem.py:565-586), one thread
+// ---------------------------------------------------------------------------------------------
+__device__ inline void commit_step(StepState* st, double ekin, double v2, double c2, int flags, LogEntry* log,
+                                   long long log_base, long long log_cap) {
+    if (flags) {
+        // invalid state: keep the pre-step field (parity not flipped) and stop (problem.py:588-610)
+        st->invalid = (flags & 1) ? 1 : 2;
+    } else {
+        const double vmax = sqrt(v2), vs = sqrt(c2);
+        const double dt_crit = st->hmin / (vmax + vs);
+        const double cfl = st->dt / dt_crit;
+        const double res = fabs(ekin - st->ekin_old) / st->ekin_old / cfl;
+        st->residual = res;
+        if (st->rcount < 5) { st->rbuf[st->rcount++] = res; }
+        else { st->rbuf[st->rhead] = res; st->rhead = (st->rhead + 1) % 5; }
+        bool conv = true;
+        for (int i = 0; i < st->rcount; ++i) conv = conv && (st->rbuf[i] < st->tol);
+        st->converged = conv ? 1 : 0;
+        st->ekin_old = ekin;
+        st->ekin = ekin; st->vmax2 = v2; st->c2max = c2;
+        st->step += 1;
+        st->simtime += st->dt;
+        if (st->adaptive) st->dt = st->CFL * dt_crit;
+        st->parity ^= 1;
+    }
+    if (log) {
+        const long long k = (flags ? st->step : st->step - 1) - log_base;
+        if (k >= 0 && k < log_cap) {
+            LogEntry e;
+            e.step = st->step; e.simtime = st->simtime; e.dt = st->dt; e.ekin = st->ekin; e.ekin_old = st->ekin_old;
+            e.residual = st->residual; e.v_max = sqrt(st->vmax2); e.v_sound = sqrt(st->c2max); e.mass = 0.0;
+            e.invalid = st->invalid; e.converged = st->converged;
+            log[k] = e;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// finish of the fused step: ghost rules on the new field, scalars over interior partials +
+// ghost cells, commit.  One block (the edge work is O(N), the stencil is O(N^2)).
+// ---------------------------------------------------------------------------------------------
+struct FinishArgs {
+    double* qa; double* qb;
+    const Partial* partials; int npartials;
+    StepState* st;
+    Layout L; Edges E;
+    LogEntry* log; long long log_base, log_cap;
+    double* out;            // if non-null: slab mode, write the 8-double local record here instead of committing
+    int honor_stop;
+};
+
+template <int EOS>
+__global__ __launch_bounds__(1024) void k_finish(const FinishArgs a, const Phys P) {
+    __shared__ Acc sm[16];
+    StepState* st = a.st;
+    if (st->invalid != 0 || (a.honor_stop && (st->converged || st->step >= st->max_it))) return;
+    const Layout& L = a.L;
+    double* q = st->parity ? a.qa : a.qb;      // the buffer k_step has just written
+    const int T = blockDim.x, t = threadIdx.x;
+
+    // 1. x ghost rows over interior columns, y ghost columns over interior rows (independent)
+    for (int iy = 1 + t; iy <= L.Ny; iy += T)
+        for (int e = 0; e < 2; ++e) {
+            if (a.E.halo[e]) continue;
+            const int ix = e == 0 ? 0 : L.Nx + 1;
+            for (int c = 0; c < 3; ++c) q[c * L.plane + L.at(ix, iy)] = ghost_x(q, L, a.E, e, c, iy);
+        }
+    for (int ix = 1 + t; ix <= L.Nx; ix += T)
+        for (int e = 2; e < 4; ++e) {
+            const int iy = e == 2 ? 0 : L.Ny + 1;
+            for (int c = 0; c < 3; ++c) q[c * L.plane + L.at(ix, iy)] = ghost_y(q, L, a.E, e, c, ix);
+        }
+    __threadfence_block();
+    __syncthreads();
+    // 2. corners: y rule applied to the freshly written ghost rows
+    if (t < 12) {
+        const int k = t / 3, c = t % 3;
+        const int ex = k & 1, ey = 2 + (k >> 1);
+        if (!a.E.halo[ex]) {
+            const int ix = ex == 0 ? 0 : L.Nx + 1, iy = ey == 2 ? 0 : L.Ny + 1;
+            q[c * L.plane + L.at(ix, iy)] = ghost_y(q, L, a.E, ey, c, ix);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // 3. scalars: ghost cells here, interior from the step kernel's per-wave records
+    Acc acc; acc.zero();
+    const double* topo_dummy = nullptr; (void)topo_dummy;
+    auto add = [&](int ix, int iy, double w) {
+        const long long o = L.at(ix, iy);
+        acc.cell<EOS>(q[o], q[o + L.plane], q[o + 2 * L.plane], 0.0, P, w);
+    };
+    for (int iy = t; iy <= L.Ny + 1; iy += T) {
+        if (!a.E.halo[0]) add(0, iy, 1.0);
+        if (!a.E.halo[1]) add(L.Nx + 1, iy, 1.0);
+    }
+    for (int ix = 1 + t; ix <= L.Nx; ix += T) {
+        // a periodic seam: the interior row next to it doubles as the far slab's ghost row, which that
+        // slab cannot sum before the exchange -- count it twice here instead
+        const double w = 1.0 + (ix == 1 && a.E.halo[0] == 2 ? 1.0 : 0.0) + (ix == L.Nx && a.E.halo[1] == 2 ? 1.0 : 0.0);
+        add(ix, 0, w);
+        add(ix, L.Ny + 1, w);
+    }
+    for (int e = 0; e < 2; ++e)
+        if (a.E.halo[e] == 2) {
+            const int ix = e == 0 ? 1 : L.Nx;
+            for (int iy = 1 + t; iy <= L.Ny; iy += T) add(ix, iy, 1.0);
+        }
+    for (int i = t; i < a.npartials; i += T) {
+        const Partial p = a.partials[i];
+        acc.ekin += p.ekin; acc.v2 = nanmax(acc.v2, p.vmax2); acc.c2 = nanmax(acc.c2, p.c2max); acc.flags |= (int)p.flags;
+    }
+    acc = block_reduce(acc, sm);
+    if (t == 0) {
+        if (a.out) {
+            // slab mode: NaN maxima travel as +inf so that any reduction order keeps them
+            const double inf = __builtin_inf();
+            a.out[0] = acc.ekin;
+            a.out[1] = acc.v2 != acc.v2 ? inf : acc.v2;
+            a.out[2] = acc.c2 != acc.c2 ? inf : acc.c2;
+            a.out[3] = (double)acc.flags;
+            a.out[4] = a.out[5] = a.out[6] = a.out[7] = 0.0;
+        } else {
+            commit_step(st, acc.ekin, acc.v2, acc.c2, acc.flags, a.log, a.log_base, a.log_cap);
+        }
+    }
+}
+
+// slab mode: halo messages <-> rows of the field the step has just produced (buffer !parity)
+struct HaloArgs {
+    double* qa; double* qb;
+    double* send_lo; double* send_hi; double* recv_lo; double* recv_hi;    // each [3][pitch]
+    const StepState* st;
+    Layout L; Edges E;
+    int honor_stop;
+};
+__global__ void k_halo_pack(const HaloArgs a) {
+    if (a.st->invalid != 0 || (a.honor_stop && (a.st->converged || a.st->step >= a.st->max_it))) return;
+    const double* q = a.st->parity ? a.qa : a.qb;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.L.pitch) return;
+    for (int c = 0; c < 3; ++c) {
+        a.send_lo[c * a.L.pitch + i] = q[c * a.L.plane + (long long)1 * a.L.pitch + i];
+        a.send_hi[c * a.L.pitch + i] = q[c * a.L.plane + (long long)a.L.Nx * a.L.pitch + i];
+    }
+}
+__global__ void k_halo_unpack(const HaloArgs a) {
+    if (a.st->invalid != 0 || (a.honor_stop && (a.st->converged || a.st->step >= a.st->max_it))) return;
+    double* q = a.st->parity ? a.qa : a.qb;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.L.pitch) return;
+    for (int c = 0; c < 3; ++c) {
+        if (a.E.halo[0]) q[c * a.L.plane + i] = a.recv_lo[c * a.L.pitch + i];
+        if (a.E.halo[1]) q[c * a.L.plane + (long long)(a.L.Nx + 1) * a.L.pitch + i] = a.recv_hi[c * a.L.pitch + i];
+    }
+}
+
+// slab mode: reduce the gathered per-slab records in rank order (identical on every rank), then commit
+__global__ void k_commit_gathered(StepState* st, const double* rec, int nranks, LogEntry* log, long long log_base,
+                                  long long log_cap, int honor_stop) {
+    if (st->invalid != 0 || (honor_stop && (st->converged || st->step >= st->max_it))) return;
+    double ekin = 0.0, v2 = 0.0, c2 = 0.0;
+    int flags = 0;
+    for (int r = 0; r < nranks; ++r) {
+        const double* p = rec + 8 * r;
+        ekin += p[0];
+        v2 = fmax(v2, p[1]); c2 = fmax(c2, p[2]);
+        flags |= (int)p[3];
+    }
+    const double inf = __builtin_inf();
+    if (v2 == inf) v2 = __builtin_nan("");
+    if (c2 == inf) c2 = __builtin_nan("");
+    commit_step(st, ekin, v2, c2, flags, log, log_base, log_cap);
+}
+
+// reduce the per-block records of k_scalars; optionally (re)initialise the step state from them
+__global__ __launch_bounds__(256) void k_scalars_final(const ScalarPartial* in, int n, ScalarPartial* out) {
+    __shared__ Acc sm[4];
+    Acc a; a.zero();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        Acc o; o.ekin = in[i].ekin; o.v2 = in[i].v2; o.c2 = in[i].c2; o.mass = in[i].mass; o.flags = (int)in[i].flags;
+        a.merge(o);
+    }
+    a = block_reduce(a, sm);
+    if (threadIdx.x == 0) {
+        ScalarPartial p = {a.ekin, a.v2, a.c2, a.mass, (double)a.flags};
+        out[0] = p;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// reference-ordered unfused pipeline, one kernel per reference function
+// ---------------------------------------------------------------------------------------------
+struct FieldPtrs {          // derived fields, padded planes
+    double* p;              // 1
+    double* tau;            // 3
+    double* lower;          // 6
+    double* upper;          // 6
+};
+
+// Pressure.update + WallStress.update (x and y objects summed) + BulkStress.update
+template <int EOS, bool HAS_LS>
+__global__ __launch_bounds__(256) void k_fields(const double* q, const double* topo, const double* Ls, FieldPtrs F,
+                                                Layout L, Phys P) {
+    const long long w = L.Ny + 2, n = (long long)(L.Nx + 2) * w;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long o = L.at((int)(i / w), (int)(i % w));
+        CellIn c;
+        c.rho = q[o]; c.jx = q[o + L.plane]; c.jy = q[o + 2 * L.plane];
+        c.h = topo[o]; c.hx = topo[o + L.plane]; c.hy = topo[o + 2 * L.plane];
+        c.Ls = HAS_LS ? Ls[o] : 0.0;
+        CellFields f;
+        cell_fields<EOS>(c, P, f);
+        F.p[o] = f.p;
+        for (int k = 0; k < 3; ++k) F.tau[o + k * L.plane] = f.tau[k];
+        for (int k = 0; k < 6; ++k) { F.lower[o + k * L.plane] = f.lower[k]; F.upper[o + k * L.plane] = f.upper[k]; }
+    }
+}
+
+// integrate.predictor_corrector: np.roll wraps over the whole (Nx+2)x(Ny+2) array (integrate.py:74-75)
+__global__ __launch_bounds__(256) void k_fluxdiff(const double* q, const double* p, const double* tau, int d, double* fx,
+                                                  double* fy, Layout L) {
+    const long long w = L.Ny + 2, n = (long long)(L.Nx + 2) * w;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int ix = (int)(i / w), iy = (int)(i % w);
+        const int ixn = (ix - d + (L.Nx + 2)) % (L.Nx + 2);      // roll(F, d)[ix] = F[ix-d]
+        const int iyn = (iy - d + (L.Ny + 2)) % (L.Ny + 2);
+        const long long o = L.at(ix, iy), ox = L.at(ixn, iy), oy = L.at(ix, iyn);
+        const double Fx0 = q[o + L.plane], Fx1 = p[o] + tau[o], Fx2 = tau[o + 2 * L.plane];
+        const double Fy0 = q[o + 2 * L.plane], Fy1 = Fx2, Fy2 = p[o] + tau[o + L.plane];
+        const double Gx0 = q[ox + L.plane], Gx1 = p[ox] + tau[ox], Gx2 = tau[ox + 2 * L.plane];
+        const double Gy0 = q[oy + 2 * L.plane], Gy1 = tau[oy + 2 * L.plane], Gy2 = p[oy] + tau[oy + L.plane];
+        const double s = -(double)d;
+        fx[o] = s * (Gx0 - Fx0); fx[o + L.plane] = s * (Gx1 - Fx1); fx[o + 2 * L.plane] = s * (Gx2 - Fx2);
+        fy[o] = s * (Gy0 - Fy0); fy[o + L.plane] = s * (Gy1 - Fy1); fy[o + 2 * L.plane] = s * (Gy2 - Fy2);
+    }
+}
+
+// integrate.source (integrate.py:117-130)
+__global__ __launch_bounds__(256) void k_source(const double* q, const double* h, const double* tau, const double* lower,
+                                                const double* upper, double* out, Layout L) {
+    const long long w = L.Ny + 2, n = (long long)(L.Nx + 2) * w, S = L.plane;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long o = L.at((int)(i / w), (int)(i % w));
+        const double h0 = h[o], hx = h[o + S], hy = h[o + 2 * S];
+        out[o] = (-q[o + S] * hx - q[o + 2 * S] * hy) / h0;
+        out[o + S] = ((tau[o] - upper[o]) * hx + (tau[o + 2 * S] - upper[o + 5 * S]) * hy + upper[o + 4 * S] - lower[o + 4 * S]) / h0;
+        out[o + 2 * S] = ((tau[o + 2 * S] - upper[o + 5 * S]) * hx + (tau[o + S] - upper[o + S]) * hy + upper[o + 3 * S] - lower[o + 3 * S]) / h0;
+    }
+}
+
+// q <- q - dt (fX/dx + fY/dy - src) over the whole array (problem.py:558)
+__global__ __launch_bounds__(256) void k_axpy(double* q, const double* fx, const double* fy, const double* src,
+                                              const StepState* st, double dx, double dy, Layout L) {
+    const double dt = st->dt;
+    const long long w = L.Ny + 2, n = (long long)(L.Nx + 2) * w;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long o = L.at((int)(i / w), (int)(i % w));
+        for (int c = 0; c < 3; ++c) {
+            const long long oc = o + c * L.plane;
+            q[oc] = q[oc] - dt * (fx[oc] / dx + fy[oc] / dy - src[oc]);
+        }
+    }
+}
+
+// q <- (q + q0)/2 (problem.py:563)
+__global__ __launch_bounds__(256) void k_average(double* q, const double* q0, Layout L) {
+    const long long w = L.Ny + 2, n = (long long)(L.Nx + 2) * w;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long o = L.at((int)(i / w), (int)(i % w));
+        for (int c = 0; c < 3; ++c) q[o + c * L.plane] = (q[o + c * L.plane] + q0[o + c * L.plane]) / 2.0;
+    }
+}
+
+__global__ void k_copy3(const double* src, double* dst, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
+// commit for the unfused path: validity is judged BEFORE the final ghost update (problem.py:565),
+// scalars after it (problem.py:576-578); both from k_scalars records.
+__global__ void k_commit_unfused(StepState* st, const ScalarPartial* pre_bc, const ScalarPartial* post_bc) {
+    int flags = (int)pre_bc->flags;
+    commit_step(st, post_bc->ekin, post_bc->v2, post_bc->c2, flags, nullptr, 0, 0);
+}
+
+}  // namespace gpf

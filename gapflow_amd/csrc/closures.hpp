@@ -1,0 +1,264 @@
+// Per-cell constitutive closures of the gap-averaged balance equations (fp64).
+//
+// Everything here is a pure function of one cell's state, usable from HIP device
+// code and from host code (tests/hostcheck builds the same header with g++).
+//
+// Reference arithmetic (paths relative to the reference root):
+//   GaPFlow/models/pressure.py:79-325   equations of state
+//   GaPFlow/models/sound.py:84-329      dp/drho
+//   GaPFlow/models/viscous.py:88-105    lower-wall stress, slip = "top"
+//   GaPFlow/models/viscous.py:333-426   upper-wall stress, slip = "top"
+//   GaPFlow/models/viscous.py:663-715   gap-averaged stress, slip = "top"
+//   GaPFlow/models/viscosity.py:150-262 piezo-viscosity
+//   GaPFlow/integrate.py:80-198         flux vectors and source term
+//
+// The solver never passes grad(q) to the stress functions (stress.py:328-344), so the
+// terms multiplying dqx/dqy vanish identically and the polynomials factor:
+//   D  = 4 Ls + h
+//   Bx = 2 Ls U rho + (h - 2 Ls) jx          (avg)       By likewise with V, jy
+//   Ax = (3 Ls + h)(3 jx - U rho)            (top wall)  Ay likewise
+//   tau_xx     = (v1 hx Bx + v2 hy By) / (h rho D)
+//   tau_xx^top = 2 (v1 hx Ax + v2 hy Ay) / (rho D^2)     ...
+// which is the same rational function as the reference's expanded form (checked against
+// the reference's own outputs in tests/golden/leaf_closures.npz to ~1e-15).
+#pragma once
+
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define GPF_HD __host__ __device__ __forceinline__
+#else
+#define GPF_HD inline
+#endif
+
+namespace gpf {
+
+enum { EOS_DH = 0, EOS_PL = 1, EOS_VDW = 2, EOS_MT = 3, EOS_CUBIC = 4, EOS_BWR = 5, EOS_BAYADA = 6 };
+enum { PIEZO_NONE = 0, PIEZO_BARUS = 1, PIEZO_ROELANDS = 2, PIEZO_DUKLER = 3, PIEZO_MCADAMS = 4 };
+
+// Material + kinematic constants, preprocessed on the host (see make_phys in api.hip).
+struct Phys {
+    double U, V, eta, zeta;
+    double inv_dx, inv_dy;
+    int eos, piezo;
+    double e[12];       // EOS constants, meaning per EOS documented in make_phys
+    double x[32];       // BWR: temperature-folded polynomial coefficients
+    double pz[4];       // piezo-viscosity constants
+};
+
+// ---- equations of state -------------------------------------------------------------------
+
+template <int EOS>
+GPF_HD double eos_pressure(double rho, const Phys& P) {
+    if (EOS == EOS_DH) {
+        // e0=rho0 e1=P0 e2=C1 e3=C2 e4=0.99*C2*rho0 (clamp) e5=1/rho0
+        double r = fmin(rho, P.e[4]);
+        double s = r * P.e[5];
+        return P.e[1] + (P.e[2] * (s - 1.0)) / (P.e[3] - s);
+    } else if (EOS == EOS_PL) {
+        // e0=rho0 e1=P0 e2=alpha e3=1/(1-alpha/2)
+        return P.e[1] * pow(rho / P.e[0], P.e[3]);
+    } else if (EOS == EOS_VDW) {
+        // e0=1000/M e1=R*T e2=a/10 e3=b/1000
+        double md = rho * P.e[0];
+        return P.e[1] * md / (1.0 - P.e[3] * md) - P.e[2] * md * md;
+    } else if (EOS == EOS_MT) {
+        // e0=rho0 e1=P0 e2=K e3=n
+        return P.e[2] / P.e[3] * (pow(rho / P.e[0], P.e[3]) - 1.0) + P.e[1];
+    } else if (EOS == EOS_CUBIC) {
+        return ((P.e[0] * rho + P.e[1]) * rho + P.e[2]) * rho + P.e[3];
+    } else if (EOS == EOS_BWR) {
+        // x[0..8]: coefficients of rho^1..rho^9 ; x[9..14]: of rho^3,5,..,13 inside exp(-gamma rho^2); e0=gamma
+        double r2 = rho * rho;
+        double poly = P.x[8];
+        for (int k = 7; k >= 0; --k) poly = poly * rho + P.x[k];
+        poly *= rho;
+        double ex = P.x[14];
+        for (int k = 13; k >= 9; --k) ex = ex * r2 + P.x[k];
+        ex *= r2 * rho;
+        return poly + exp(-P.e[0] * r2) * ex;
+    } else {
+        // Bayada-Chupin: e0=rho_l e1=rho_v e2=c_l^2 e3=c_v^2 e4=N e5=Pcav e6=1/(rho_v-rho_l)
+        double alpha = (rho - P.e[0]) * P.e[6];
+        if (alpha < 0.0) return P.e[5] + (rho - P.e[0]) * P.e[2];
+        if (alpha <= 1.0) {
+            double den = P.e[0] * (P.e[1] * P.e[3] * (1.0 - alpha) + P.e[0] * P.e[2] * alpha);
+            return P.e[5] + P.e[4] * log(P.e[1] * P.e[3] * rho / den);
+        }
+        return P.e[3] * rho;
+    }
+}
+
+// dp/drho (the square of the sound speed); NaN/negative values propagate like np.sqrt would.
+template <int EOS>
+GPF_HD double eos_c2(double rho, const Phys& P) {
+    if (EOS == EOS_DH) {
+        // C1 rho0 (C2-1) / rho^2 / (C2 rho0/rho - 1)^2, *unclamped* rho (sound.py:109)
+        double ir = 1.0 / rho;
+        double t = P.e[3] * P.e[0] * ir - 1.0;
+        return P.e[6] * (ir * ir) / (t * t);          // e6 = C1*rho0*(C2-1)
+    } else if (EOS == EOS_PL) {
+        // -2 P0 (rho/rho0)^(-2/(alpha-2)) / ((alpha-2) rho)
+        return -2.0 * P.e[1] * pow(rho / P.e[0], -2.0 / (P.e[2] - 2.0)) / ((P.e[2] - 2.0) * rho);
+    } else if (EOS == EOS_VDW) {
+        double md = rho * P.e[0];
+        double t = 1.0 - P.e[3] * md;
+        return P.e[1] / (t * t) - 2.0 * P.e[2] * md;
+    } else if (EOS == EOS_MT) {
+        return P.e[2] / pow(P.e[0], P.e[3]) * pow(rho, P.e[3] - 1.0);
+    } else if (EOS == EOS_CUBIC) {
+        return (3.0 * P.e[0] * rho + 2.0 * P.e[1]) * rho + P.e[2];
+    } else if (EOS == EOS_BWR) {
+        double r2 = rho * rho;
+        // d/drho of sum_{k=1..9} x[k-1] rho^k
+        double dpoly = 9.0 * P.x[8];
+        for (int k = 7; k >= 0; --k) dpoly = dpoly * rho + (double)(k + 1) * P.x[k];
+        // exp part: E(rho) = sum_{m=0..5} x[9+m] rho^(3+2m)
+        double ex = P.x[14], dex = 13.0 * P.x[14];
+        for (int m = 4; m >= 0; --m) {
+            ex = ex * r2 + P.x[9 + m];
+            dex = dex * r2 + (double)(3 + 2 * m) * P.x[9 + m];
+        }
+        ex *= r2 * rho;     // E
+        dex *= r2;          // E'
+        double g = exp(-P.e[0] * r2);
+        return dpoly + g * dex - 2.0 * rho * P.e[0] * g * ex;
+    } else {
+        double alpha = (rho - P.e[0]) * P.e[6];
+        if (alpha < 0.0) return P.e[2];
+        if (alpha <= 1.0)
+            return P.e[1] * P.e[0] * (P.e[3] * P.e[2]) / (alpha * P.e[0] * P.e[2] + (1.0 - alpha) * P.e[1] * P.e[3]) / rho;
+        return P.e[3];
+    }
+}
+
+// ---- viscosity ----------------------------------------------------------------------------
+
+// `arg` is the pressure, or the density when the EOS is Bayada-Chupin (stress.py:307-310)
+GPF_HD double piezo_eta(double eta0, double arg, const Phys& P) {
+    switch (P.piezo) {
+    case PIEZO_BARUS:    return eta0 * exp(P.pz[0] * arg);
+    case PIEZO_ROELANDS: return eta0 * exp(P.pz[3] * (-1.0 + pow(1.0 + arg / P.pz[1], P.pz[2])));   // pz3 = ln(mu0/mu_inf)
+    case PIEZO_DUKLER: {
+        double a = (arg - P.pz[1]) / (P.pz[2] - P.pz[1]);
+        return a * P.pz[0] + (1.0 - a) * eta0;
+    }
+    case PIEZO_MCADAMS: {
+        double a = (arg - P.pz[1]) / (P.pz[2] - P.pz[1]);
+        double M = a * P.pz[2] / arg;
+        return P.pz[0] * eta0 / (eta0 * M + P.pz[0] * (1.0 - M));
+    }
+    default: return eta0;
+    }
+}
+
+// ---- one cell: fluxes and source ------------------------------------------------------------
+
+struct CellIn {
+    double rho, jx, jy;     // q
+    double h, hx, hy;       // gap height and slopes
+    double Ls;              // slip length ('extra' field)
+};
+
+// F_x = (jx, p + tau_xx, tau_xy), F_y = (jy, tau_xy, p + tau_yy)  (integrate.py:133-198)
+struct CellFlux {
+    double fx1, fx2;        // p + tau_xx, tau_xy   (fx0 = jx)
+    double fy2;             // p + tau_yy           (fy0 = jy, fy1 = tau_xy = fx2)
+    double s0, s1, s2;      // source term (integrate.py:117-130)
+    double p;
+};
+
+// Gap-averaged stress, both wall stresses, pressure: everything a stage needs from one cell.
+template <int EOS, bool WITH_SOURCE>
+GPF_HD void cell_closure(const CellIn& c, const Phys& P, CellFlux& o) {
+    const double U = P.U, V = P.V;
+    const double p = eos_pressure<EOS>(c.rho, P);
+    const double eta = (P.piezo == PIEZO_NONE) ? P.eta : piezo_eta(P.eta, (EOS == EOS_BAYADA) ? c.rho : p, P);
+    const double v1 = P.zeta + (4.0 / 3.0) * eta;
+    const double v2 = P.zeta - (2.0 / 3.0) * eta;
+
+    const double D = 4.0 * c.Ls + c.h;
+    const double ih = 1.0 / c.h, ir = 1.0 / c.rho, iD = 1.0 / D;
+    const double irD = ir * iD;         // 1/(rho D)
+    const double ihrD = ih * irD;       // 1/(h rho D)
+
+    const double Urho = U * c.rho, Vrho = V * c.rho;
+    const double hm = c.h - 2.0 * c.Ls;
+    const double Bx = 2.0 * c.Ls * Urho + hm * c.jx;
+    const double By = 2.0 * c.Ls * Vrho + hm * c.jy;
+    const double hxBx = c.hx * Bx, hyBy = c.hy * By;
+    const double txx = (v1 * hxBx + v2 * hyBy) * ihrD;
+    const double tyy = (v2 * hxBx + v1 * hyBy) * ihrD;
+    const double txy = eta * (c.hy * Bx + c.hx * By) * ihrD;
+
+    o.p = p;
+    o.fx1 = p + txx;
+    o.fx2 = txy;
+    o.fy2 = p + tyy;
+
+    if (WITH_SOURCE) {
+        const double w = 3.0 * c.Ls + c.h;
+        const double gx = 3.0 * c.jx - Urho, gy = 3.0 * c.jy - Vrho;
+        const double Ax = w * gx, Ay = w * gy;
+        const double t2 = 2.0 * irD * iD;                         // 2/(rho D^2)
+        const double hxAx = c.hx * Ax, hyAy = c.hy * Ay;
+        const double txx_t = (v1 * hxAx + v2 * hyAy) * t2;
+        const double tyy_t = (v2 * hxAx + v1 * hyAy) * t2;
+        const double txy_t = eta * (c.hy * Ax + c.hx * Ay) * t2;
+        const double e2 = 2.0 * eta * irD;                        // 2 eta/(rho D)
+        const double txz_t = -e2 * gx;                            // 2 eta (U rho - 3 jx)/(rho D)
+        const double tyz_t = -e2 * gy;
+        // bottom: 2 eta [(6Ls+3h) j - (6Ls+2h) W rho] / (h rho D)
+        const double a3 = 6.0 * c.Ls + 3.0 * c.h, a2 = 6.0 * c.Ls + 2.0 * c.h;
+        const double e2h = e2 * ih;
+        const double txz_b = e2h * (a3 * c.jx - a2 * Urho);
+        const double tyz_b = e2h * (a3 * c.jy - a2 * Vrho);
+
+        o.s0 = -(c.jx * c.hx + c.jy * c.hy) * ih;
+        o.s1 = ((txx - txx_t) * c.hx + (txy - txy_t) * c.hy + txz_t - txz_b) * ih;
+        o.s2 = ((txy - txy_t) * c.hx + (tyy - tyy_t) * c.hy + tyz_t - tyz_b) * ih;
+    }
+}
+
+// The full set of derived fields the reference keeps per cell (for gpf_update_closures).
+struct CellFields {
+    double p;
+    double tau[3];          // xx, yy, xy
+    double lower[6];        // Voigt xx,yy,zz,yz,xz,xy
+    double upper[6];
+};
+
+template <int EOS>
+GPF_HD void cell_fields(const CellIn& c, const Phys& P, CellFields& o) {
+    const double U = P.U, V = P.V;
+    const double p = eos_pressure<EOS>(c.rho, P);
+    const double eta = (P.piezo == PIEZO_NONE) ? P.eta : piezo_eta(P.eta, (EOS == EOS_BAYADA) ? c.rho : p, P);
+    const double v1 = P.zeta + (4.0 / 3.0) * eta;
+    const double v2 = P.zeta - (2.0 / 3.0) * eta;
+    const double D = 4.0 * c.Ls + c.h;
+    const double den = c.h * c.rho * D;
+    const double Urho = U * c.rho, Vrho = V * c.rho;
+    const double hm = c.h - 2.0 * c.Ls;
+    const double Bx = 2.0 * c.Ls * Urho + hm * c.jx;
+    const double By = 2.0 * c.Ls * Vrho + hm * c.jy;
+    o.p = p;
+    o.tau[0] = (v1 * c.hx * Bx + v2 * c.hy * By) / den;
+    o.tau[1] = (v2 * c.hx * Bx + v1 * c.hy * By) / den;
+    o.tau[2] = eta * (c.hy * Bx + c.hx * By) / den;
+    const double w = 3.0 * c.Ls + c.h;
+    const double gx = 3.0 * c.jx - Urho, gy = 3.0 * c.jy - Vrho;
+    const double Ax = w * gx, Ay = w * gy;
+    const double dT = c.rho * D * D;
+    o.upper[0] = 2.0 * (v1 * c.hx * Ax + v2 * c.hy * Ay) / dT;
+    o.upper[1] = 2.0 * (v2 * c.hx * Ax + v1 * c.hy * Ay) / dT;
+    o.upper[2] = 2.0 * v2 * (c.hx * Ax + c.hy * Ay) / dT;
+    o.upper[3] = -2.0 * eta * gy / (c.rho * D);
+    o.upper[4] = -2.0 * eta * gx / (c.rho * D);
+    o.upper[5] = 2.0 * eta * (c.hy * Ax + c.hx * Ay) / dT;
+    const double a3 = 6.0 * c.Ls + 3.0 * c.h, a2 = 6.0 * c.Ls + 2.0 * c.h;
+    o.lower[0] = o.lower[1] = o.lower[2] = o.lower[5] = 0.0;
+    o.lower[3] = 2.0 * eta * (a3 * c.jy - a2 * Vrho) / den;
+    o.lower[4] = 2.0 * eta * (a3 * c.jx - a2 * Urho) / den;
+}
+
+}  // namespace gpf

@@ -1,0 +1,320 @@
+// Fused MacCormack step for gfx950: both stages, the time average and the per-step
+// reductions in ONE pass over HBM.
+//
+// Replaces, per time step (paths relative to the reference root):
+//   GaPFlow/problem.py:528-563          q0 copy, two stages, (q + q0)/2
+//   GaPFlow/models/stress.py:289-362, 427-459, 600-622   closures, twice per step
+//   GaPFlow/integrate.py:38-130         flux differences + source, twice per step
+//   GaPFlow/problem.py:319-357          NaN / rho<0 checks, Ekin, v_max, v_sound
+//
+// Why one pass is possible: the predictor differences upwind (F[n]-F[n-1]) and the corrector
+// downwind (F[n+1]-F[n]); the composed stencil of a full step is
+//   (n-1,m) (n,m-1) (n,m) (n+1,m) (n,m+1) (n+1,m-1) (n-1,m+1)
+// i.e. radius 1.  So a step needs q and the topography once (read) and q once (write):
+// 72 B per cell (80 B with a slip-length field) -- the algorithmic minimum of BASELINE.md.
+//
+// Mapping to the hardware
+//   * one 64-lane wavefront owns a strip of 62 output columns (iy, the contiguous axis) and
+//     marches along ix over a chunk of rows.  Lane l holds column m0-1+l, so lanes 0 and 63
+//     are the strip's halo columns and every global access of the wave is one contiguous
+//     512-B segment per plane.
+//   * y-neighbours come from the adjacent lane through wavefront shuffles (`__shfl_up/down`,
+//     ds_bpermute: no LDS allocation, no barrier); x-neighbours are the wave's own registers
+//     from the previous row.  Waves never synchronise, so a 256-thread block is just four
+//     adjacent strips that share their halo lines in the CU's L1.
+//   * each cell's closure is evaluated exactly twice per step (once per stage) plus the halo
+//     lanes/rows (2/64 columns, 2/rows_per_chunk rows).
+//   * rows n+1 are requested before row n is computed (the loads below sit one iteration
+//     ahead), so ~7 planes x 512 B per wave are always in flight.
+//
+// "Logical" indices: n (rows) and m (columns) always increase DOWNWIND of the predictor:
+//   ix = n for D=+1, Nx+1-n for D=-1  (likewise iy from m).
+// In these coordinates both MC orders run the same code; only the sign D of the one-sided
+// differences and the address mapping change (problem.py:521-522).
+//
+// Ghost cells.  Stage-1 input is whatever the array holds (including ghost cells the user
+// may have left stale, tests/test_wave_decay.py:101).  The stage-1 RESULT at a physical
+// downwind ghost (row Nx+1 / column Ny+1 in logical terms) is not computed by the stencil
+// but follows the ghost rule applied to the stage-1 field (problem.py:560); those values
+// are prepared by k_ghost_stage1 into g1x / g1y and picked up here.
+#include <hip/hip_runtime.h>
+#include "device_types.hpp"
+
+namespace gpf {
+
+constexpr int STRIP = 62;       // output columns per wavefront
+
+struct StepArgs {
+    const double* qa;           // q buffer 0 (3 planes)
+    const double* qb;           // q buffer 1
+    const double* topo;         // h, hx, hy planes
+    const double* Ls;           // slip-length plane or nullptr
+    const double* g1x;          // [3][pitch]  stage-1 field on the downwind physical ghost row
+    const double* g1y;          // [3][Nx+2]   ... on the downwind physical ghost column
+    const StepState* st;
+    Partial* partials;          // one per (chunk, strip)
+    Layout L;
+    Edges E;
+    int rows_per_chunk;
+    int nstrips;
+    int honor_stop;
+};
+
+__device__ __forceinline__ bool halted(const StepState* st, int honor_stop) {
+    return st->invalid != 0 || (honor_stop && (st->converged || st->step >= st->max_it));
+}
+
+// direction of the predictor for the step about to run (problem.py:521-522)
+__device__ __forceinline__ int predictor_direction(const StepState* st) {
+    if (st->mc_order == 0) return (st->step % 2 == 0) ? 1 : -1;
+    return ((st->mc_order + 1) / 2) ? 1 : -1;      // [[-1,1],[1,-1]][(switch+1)//2]
+}
+
+template <int EOS, bool HAS_LS, int D>
+__device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, const double* __restrict__ qin,
+                                           double* __restrict__ qout) {
+    const Layout L = a.L;
+    const int lane = threadIdx.x & 63;
+    const int strip = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (strip >= a.nstrips) return;                         // wave-uniform
+    const int chunk = blockIdx.y;
+
+    // columns
+    const int m_raw = strip * STRIP + lane;                 // logical column, 0 = upwind ghost
+    const int m = m_raw <= L.Ny + 1 ? m_raw : L.Ny + 1;
+    const int iy = D > 0 ? m : L.Ny + 1 - m;
+    const bool col_out = lane >= 1 && lane <= STRIP && m_raw >= 1 && m_raw <= L.Ny;
+    const bool col_dw_ghost = (m_raw == L.Ny + 1);          // physical downwind ghost column
+    // rows of this chunk: outputs n_first..n_last, marching n_first-1 .. n_last+1
+    const int n_first = chunk * a.rows_per_chunk + 1;
+    const int n_last = min(n_first + a.rows_per_chunk - 1, L.Nx);
+    const bool dw_row_is_ghost = (n_last == L.Nx) && a.E.halo[D > 0 ? 1 : 0] != 1;
+
+    const double dt = a.st->dt;
+    const double cx = (double)D * P.inv_dx, cy = (double)D * P.inv_dy;
+
+    const double* __restrict__ q0p = qin;
+    const double* __restrict__ q1p = qin + L.plane;
+    const double* __restrict__ q2p = qin + 2 * L.plane;
+    const double* __restrict__ hp = a.topo;
+    const double* __restrict__ hxp = a.topo + L.plane;
+    const double* __restrict__ hyp = a.topo + 2 * L.plane;
+
+    auto load = [&](int n, CellIn& c) {
+        const int ix = D > 0 ? n : L.Nx + 1 - n;
+        const long long o = L.at(ix, iy);
+        c.rho = q0p[o]; c.jx = q1p[o]; c.jy = q2p[o];
+        c.h = hp[o]; c.hx = hxp[o]; c.hy = hyp[o];
+        c.Ls = HAS_LS ? a.Ls[o] : 0.0;
+    };
+
+    CellIn cur, nxt;
+    load(n_first - 1, cur);
+
+    // carried from the previous row
+    double fx1p0 = 0, fx1p1 = 0, fx1p2 = 0;     // stage-1 x-flux of row n-1
+    double part0 = 0, part1 = 0, part2 = 0;     // row n-1: q1 - dt*(-cx*Fx2 + cy*dFy2 - S2)
+    double a0 = 0, a1 = 0, a2 = 0;              // row n-1: q at time level 0
+    // reductions over this wave's output cells
+    double r_ekin = 0.0, r_v2 = 0.0, r_c2 = 0.0;
+    int r_flags = 0;
+
+    for (int n = n_first - 1; n <= n_last + 1; ++n) {
+        if (n <= n_last) load(n + 1, nxt);                  // one row ahead
+        const bool first = (n == n_first - 1);
+        const bool last = (n == n_last + 1);
+        const int ix = D > 0 ? n : L.Nx + 1 - n;
+
+        // ---- stage 1 at (n, m) ----
+        double q10, q11, q12;
+        if (last && dw_row_is_ghost) {
+            q10 = a.g1x[0 * L.pitch + L.off + iy];
+            q11 = a.g1x[1 * L.pitch + L.off + iy];
+            q12 = a.g1x[2 * L.pitch + L.off + iy];
+        } else {
+            CellFlux f;
+            cell_closure<EOS, true>(cur, P, f);
+            const double fy0 = cur.jy, fy1 = f.fx2, fy2 = f.fy2;
+            const double u0 = __shfl_up(fy0, 1), u1 = __shfl_up(fy1, 1), u2 = __shfl_up(fy2, 1);
+            q10 = cur.rho - dt * (cx * (cur.jx - fx1p0) + cy * (fy0 - u0) - f.s0);
+            q11 = cur.jx - dt * (cx * (f.fx1 - fx1p1) + cy * (fy1 - u1) - f.s1);
+            q12 = cur.jy - dt * (cx * (f.fx2 - fx1p2) + cy * (fy2 - u2) - f.s2);
+            fx1p0 = cur.jx; fx1p1 = f.fx1; fx1p2 = f.fx2;
+            if (col_dw_ghost) {
+                q10 = a.g1y[0 * (L.Nx + 2) + ix];
+                q11 = a.g1y[1 * (L.Nx + 2) + ix];
+                q12 = a.g1y[2 * (L.Nx + 2) + ix];
+            }
+        }
+
+        if (!first) {
+            // ---- stage 2 closure at (n, m) on the stage-1 field ----
+            CellIn c1 = cur;
+            c1.rho = q10; c1.jx = q11; c1.jy = q12;
+            CellFlux g;
+            cell_closure<EOS, true>(c1, P, g);
+            const double gy0 = q12, gy1 = g.fx2, gy2 = g.fy2;
+            const double d0 = __shfl_down(gy0, 1), d1 = __shfl_down(gy1, 1), d2 = __shfl_down(gy2, 1);
+
+            // ---- finish row n-1: corrector + time average (problem.py:558, 563) ----
+            if (n > n_first) {
+                const double o0 = 0.5 * ((part0 - dt * cx * q11) + a0);
+                const double o1 = 0.5 * ((part1 - dt * cx * g.fx1) + a1);
+                const double o2 = 0.5 * ((part2 - dt * cx * g.fx2) + a2);
+                if (col_out) {
+                    const int ixo = D > 0 ? n - 1 : L.Nx + 2 - n;
+                    const long long o = L.at(ixo, iy);
+                    qout[o] = o0;
+                    qout[o + L.plane] = o1;
+                    qout[o + 2 * L.plane] = o2;
+                    const double v2 = (o1 * o1 + o2 * o2) / o0;
+                    r_ekin += v2 * 0.5;
+                    r_v2 = nanmax(r_v2, v2);
+                    double c2 = eos_c2<EOS>(o0, P);
+                    c2 = (c2 < 0.0) ? __builtin_nan("") : c2;
+                    r_c2 = nanmax(r_c2, c2);
+                    if (o0 != o0 || o1 != o1 || o2 != o2) r_flags |= 1;
+                    if (o0 < 0.0) r_flags |= 2;
+                }
+            }
+            // ---- open row n (an output row unless this is the downwind extra row) ----
+            part0 = q10 - dt * (-cx * q11 + cy * (d0 - gy0) - g.s0);
+            part1 = q11 - dt * (-cx * g.fx1 + cy * (d1 - gy1) - g.s1);
+            part2 = q12 - dt * (-cx * g.fx2 + cy * (d2 - gy2) - g.s2);
+            a0 = cur.rho; a1 = cur.jx; a2 = cur.jy;
+        }
+        cur = nxt;
+    }
+
+    // ---- wave reduction, one record per wave ----
+    for (int s = 32; s >= 1; s >>= 1) {
+        r_ekin += __shfl_down(r_ekin, s);
+        r_v2 = nanmax(r_v2, __shfl_down(r_v2, s));
+        r_c2 = nanmax(r_c2, __shfl_down(r_c2, s));
+        r_flags |= __shfl_down(r_flags, s);
+    }
+    if (lane == 0) {
+        Partial p;
+        p.ekin = r_ekin; p.vmax2 = r_v2; p.c2max = r_c2; p.flags = (double)r_flags;
+        a.partials[(long long)chunk * a.nstrips + strip] = p;
+    }
+}
+
+template <int EOS, bool HAS_LS>
+__global__ __launch_bounds__(256) void k_step(const StepArgs a, const Phys P) {
+    if (halted(a.st, a.honor_stop)) return;
+    const int par = a.st->parity;
+    const double* qin = par ? a.qb : a.qa;
+    double* qout = const_cast<double*>(par ? a.qa : a.qb);
+    if (predictor_direction(a.st) > 0)
+        step_strip<EOS, HAS_LS, 1>(a, P, qin, qout);
+    else
+        step_strip<EOS, HAS_LS, -1>(a, P, qin, qout);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage-1 values on the physical downwind ghost row / column (problem.py:560 after stage 1):
+//   periodic : q1(ghost) = q1(partner), partner = first interior cell on the other side
+//   Neumann  : q1(ghost) = q1(adjacent)                (problem.py:766)
+//   Dirichlet: q1(ghost) = 2*target - q1(adjacent)     (problem.py:758-764)
+// q1 at the source cell is the ordinary predictor result there, from the stored field.
+// ---------------------------------------------------------------------------------------------
+struct GhostArgs {
+    const double* qa; const double* qb;
+    const double* topo; const double* Ls;
+    const double* seam[2];      // per x edge: [2 rows][4: h,hx,hy,Ls][pitch] = topography of (source row, its
+                                // upwind row) on the far side of a periodic slab seam, or nullptr
+    double* g1x; double* g1y;
+    const StepState* st;
+    Layout L; Edges E;
+    int honor_stop;
+};
+
+template <int EOS, bool HAS_LS>
+__device__ __forceinline__ void stage1_at(const double* __restrict__ q, const GhostArgs& a, const Phys& P, int D,
+                                          int ix, int iy, const double* tsrc, const double* tup, const double* lsrc,
+                                          const double* lup, int ixq_up, double dt, double out[3]) {
+    // (ix, iy): source cell; x-upwind neighbour is (ix - D, iy) -- or row ixq_up of q when the caller
+    // redirects it across a slab seam; y-upwind neighbour is (ix, iy - D).  tsrc/tup: optional topo rows.
+    const Layout& L = a.L;
+    auto cell = [&](int cx_, int cy_, const double* trow, const double* lrow, CellIn& c) {
+        const long long o = L.at(cx_, cy_);
+        c.rho = q[o]; c.jx = q[o + L.plane]; c.jy = q[o + 2 * L.plane];
+        if (trow) {
+            c.h = trow[L.off + cy_]; c.hx = trow[L.pitch + L.off + cy_]; c.hy = trow[2 * L.pitch + L.off + cy_];
+            c.Ls = (HAS_LS && lrow) ? lrow[L.off + cy_] : 0.0;
+        } else {
+            c.h = a.topo[o]; c.hx = a.topo[o + L.plane]; c.hy = a.topo[o + 2 * L.plane];
+            c.Ls = HAS_LS ? a.Ls[o] : 0.0;
+        }
+    };
+    CellIn c, cxu, cyu;
+    cell(ix, iy, tsrc, lsrc, c);
+    cell(ixq_up, iy, tup, lup, cxu);
+    cell(ix, iy - D, tsrc, lsrc, cyu);
+    CellFlux f, fxu, fyu;
+    cell_closure<EOS, true>(c, P, f);
+    cell_closure<EOS, false>(cxu, P, fxu);
+    cell_closure<EOS, false>(cyu, P, fyu);
+    const double cx = (double)D * P.inv_dx, cy = (double)D * P.inv_dy;
+    out[0] = c.rho - dt * (cx * (c.jx - cxu.jx) + cy * (c.jy - cyu.jy) - f.s0);
+    out[1] = c.jx - dt * (cx * (f.fx1 - fxu.fx1) + cy * (f.fx2 - fyu.fx2) - f.s1);
+    out[2] = c.jy - dt * (cx * (f.fx2 - fxu.fx2) + cy * (f.fy2 - fyu.fy2) - f.s2);
+}
+
+template <int EOS, bool HAS_LS>
+__global__ __launch_bounds__(256) void k_ghost_stage1(const GhostArgs a, const Phys P) {
+    if (halted(a.st, a.honor_stop)) return;
+    const Layout& L = a.L;
+    const double* q = a.st->parity ? a.qb : a.qa;
+    const int D = predictor_direction(a.st);
+    const double dt = a.st->dt;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[3];
+    if (blockIdx.y == 0) {
+        // downwind ghost ROW, interior columns
+        const int edge = D > 0 ? 1 : 0;
+        if (a.E.halo[edge] == 1) return;       // a neighbour's real cell: the stencil computes it
+        const int iy = t + 1;
+        if (iy > L.Ny) return;
+        const bool periodic = a.E.rule[edge][0] == BC_P;
+        // source row in the stored field
+        int ix_src, ix_up;
+        const double *ts = nullptr, *tu = nullptr, *ls = nullptr, *lu = nullptr;
+        if (!periodic) {
+            ix_src = D > 0 ? L.Nx : 1;
+            ix_up = ix_src - D;
+        } else if (a.E.halo[edge] != 2) {
+            ix_src = D > 0 ? 1 : L.Nx;              // partner cell on the other side of the domain
+            ix_up = ix_src - D;
+        } else {
+            // periodic seam between slabs: the partner row's q sits in this slab's halo/ghost row,
+            // its upwind neighbour is this slab's last interior row; their topography is static data
+            ix_src = D > 0 ? L.Nx + 1 : 0;
+            ix_up = D > 0 ? L.Nx : 1;
+            ts = a.seam[edge]; tu = a.seam[edge] + 4 * L.pitch;
+            ls = ts + 3 * L.pitch; lu = tu + 3 * L.pitch;
+        }
+        stage1_at<EOS, HAS_LS>(q, a, P, D, ix_src, iy, ts, tu, ls, lu, ix_up, dt, v);
+        for (int c = 0; c < 3; ++c) {
+            const int r = a.E.rule[edge][c];
+            const double g = (r == BC_D) ? 2.0 * a.E.value[edge] - v[c] : v[c];
+            a.g1x[c * L.pitch + L.off + iy] = g;
+        }
+    } else {
+        // downwind ghost COLUMN, interior rows
+        const int edge = D > 0 ? 3 : 2;
+        const int ix = t + 1;
+        if (ix > L.Nx) return;
+        const bool periodic = a.E.rule[edge][0] == BC_P;
+        const int iy_src = periodic ? (D > 0 ? 1 : L.Ny) : (D > 0 ? L.Ny : 1);
+        stage1_at<EOS, HAS_LS>(q, a, P, D, ix, iy_src, nullptr, nullptr, nullptr, nullptr, ix - D, dt, v);
+        for (int c = 0; c < 3; ++c) {
+            const int r = a.E.rule[edge][c];
+            const double g = (r == BC_D) ? 2.0 * a.E.value[edge] - v[c] : v[c];
+            a.g1y[c * (L.Nx + 2) + ix] = g;
+        }
+    }
+}
+
+}  // namespace gpf

@@ -1,0 +1,177 @@
+/*
+ * gapflow_hip.h -- C ABI of libgapflow_hip.so, the MI355X (gfx950) implementation of
+ * GaPFlow's explicit time-integration hot path.
+ *
+ * The reference (hannes-holey/GaPFlow) has no FFI for this path: the boundary is its
+ * Python API (GaPFlow/problem.py, GaPFlow/integrate.py).  Every entry point below names
+ * the reference code it replaces (paths relative to the reference root).  The host side
+ * (gapflow_amd/problem.py, gapflow_amd/integrate.py) binds these with ctypes; see
+ * INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success or a negative gpf_status;
+ *     nothing throws across the boundary; gpf_last_error() gives the message of the
+ *     last failure on the calling thread.
+ *   - host arrays are BORROWED for the duration of the call and use the reference's
+ *     layout: C-contiguous double[ncomp][Nx+2][Ny+2], one ghost cell per side
+ *     (problem.py:122-141).  The library owns all device memory.
+ *   - a handle is not thread-safe; all work of a handle is issued on one HIP stream.
+ *   - all arithmetic is IEEE binary64 ("f64").
+ */
+#ifndef GAPFLOW_HIP_H
+#define GAPFLOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gpf_handle gpf_handle;
+
+typedef enum {
+    GPF_OK = 0,
+    GPF_ERR_INVALID = -1,     /* bad argument / unsupported configuration */
+    GPF_ERR_HIP = -2,         /* HIP runtime error (message has hipGetErrorString) */
+    GPF_ERR_NO_DEVICE = -3,   /* no gfx950 device visible */
+    GPF_ERR_SOLVER = -4,      /* rocSOLVER / rocBLAS failure, or matrix not positive definite */
+    GPF_ERR_STATE = -5        /* call sequence error (e.g. step before upload) */
+} gpf_status;
+
+/* Equation of state ids (GaPFlow/models/pressure.py:51-71) */
+enum { GPF_EOS_DH = 0, GPF_EOS_PL = 1, GPF_EOS_VDW = 2, GPF_EOS_MT = 3,
+       GPF_EOS_CUBIC = 4, GPF_EOS_BWR = 5, GPF_EOS_BAYADA = 6 };
+
+/* Ghost-cell rule per component (GaPFlow/problem.py:676-768) */
+enum { GPF_BC_PERIODIC = 0, GPF_BC_DIRICHLET = 1, GPF_BC_NEUMANN = 2 };
+
+/* Piezo-viscosity laws (GaPFlow/models/viscosity.py:34-66) */
+enum { GPF_PIEZO_NONE = 0, GPF_PIEZO_BARUS = 1, GPF_PIEZO_ROELANDS = 2,
+       GPF_PIEZO_DUKLER = 3, GPF_PIEZO_MCADAMS = 4 };
+
+/* Field ids for gpf_upload / gpf_download */
+enum {
+    GPF_FIELD_Q = 0,          /* 3 comps: rho, jx, jy                 (problem.py:128)          */
+    GPF_FIELD_TOPO = 1,       /* 3 comps: h, dh/dx, dh/dy             (topography.py:252-254)   */
+    GPF_FIELD_EXTRA = 2,      /* 1 comp : slip length Ls              (problem.py:132-135)      */
+    GPF_FIELD_PRESSURE = 3,   /* 1 comp : derived, stress.py:600-622                            */
+    GPF_FIELD_TAU_AVG = 4,    /* 3 comps: xx, yy, xy, stress.py:427-459                         */
+    GPF_FIELD_WALL_LOWER = 5, /* 6 comps Voigt = wall_stress_xz.lower + wall_stress_yz.lower    */
+    GPF_FIELD_WALL_UPPER = 6  /* 6 comps Voigt (problem.py:554-555)                             */
+};
+
+/*
+ * Static description of one problem (or of one x-slab of it).  Mirrors the sanitised
+ * dicts of GaPFlow/io.py:128-394 after the host has resolved the boundary-condition
+ * side quirks of problem.py:736-754 into "rule and target of each ghost edge".
+ */
+typedef struct {
+    int32_t Nx, Ny;            /* interior cells of this slab; arrays are (Nx+2) x (Ny+2)          */
+    double  dx, dy;
+    double  U, V;              /* wall velocities, geometry dict                                    */
+    double  eta, zeta;         /* shear / bulk viscosity, properties dict                           */
+    int32_t eos;               /* GPF_EOS_*                                                         */
+    double  eos_par[8];        /* DH: rho0,P0,C1,C2 | PL: rho0,P0,alpha | vdW: M,T,a,b |
+                                  MT: rho0,P0,K,n | cubic: a,b,c,d | BWR: T,gamma |
+                                  Bayada: rho_l,rho_v,c_l,c_v                                        */
+    int32_t piezo;             /* GPF_PIEZO_*                                                       */
+    double  piezo_par[4];      /* Barus: aB | Roelands: mu_inf,p_ref,z | Dukler/McAdams: eta_v,rho_l,rho_v */
+    /* ghost edges: [0]=ix=0, [1]=ix=Nx+1, [2]=iy=0, [3]=iy=Ny+1; rule per component            */
+    int32_t bc_rule[4][3];
+    double  bc_value[4];       /* Dirichlet target of that edge (one scalar per edge)              */
+    int32_t halo_lo, halo_hi;  /* kind of the rows ix=0 / ix=Nx+1 of this slab:
+                                  0 physical ghost row (rule above applied locally),
+                                  1 slab halo = copy of a neighbour's interior row (caller's exchange),
+                                  2 periodic seam = the domain's periodic ghost row, filled by the
+                                    caller's ring exchange instead of a local copy                    */
+    /* time stepping (io.py:381-394, problem.py:412-443) */
+    int32_t adaptive;
+    double  CFL, dt_fixed, tol;
+    int64_t max_it;
+    int32_t mc_order;          /* +1, -1, or 0 = alternate by step parity (problem.py:521-522)     */
+    int32_t device;            /* HIP device ordinal                                                */
+} gpf_config;
+
+/* Per-step scalars (problem.py:334-362, 571-586).  All sums/maxima run over the whole
+ * array including ghost cells, as in the reference. */
+typedef struct {
+    int64_t step;
+    double  simtime, dt;       /* dt = step size the NEXT step will use                             */
+    double  ekin, ekin_old;    /* Ekin = sum (jx^2+jy^2)/rho/2                                      */
+    double  residual;          /* |Ekin-Ekin_old|/Ekin_old/cfl                                      */
+    double  v_max, v_sound;    /* max sqrt((jx^2+jy^2)/rho) (sic), max c(rho)                       */
+    double  mass;              /* sum rho*h*dx*dy; filled by gpf_scalars only                       */
+    int32_t invalid;           /* 1: NaN, 2: negative density (problem.py:319-332)                 */
+    int32_t converged;         /* all of the last <=5 residuals < tol (problem.py:359-362)          */
+} gpf_scalars_t;
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+int gpf_create(const gpf_config* cfg, gpf_handle** out);      /* Problem.__init__, problem.py:77-151 */
+int gpf_destroy(gpf_handle* h);
+int gpf_set_stream(gpf_handle* h, void* hip_stream);          /* default: the null stream           */
+const char* gpf_last_error(void);
+int gpf_device_count(void);
+
+/* ---- fields ---------------------------------------------------------------------------- */
+int gpf_upload(gpf_handle* h, int field, const double* host, size_t count);     /* count = ncomp*(Nx+2)*(Ny+2) */
+int gpf_download(gpf_handle* h, int field, double* host, size_t count);
+/* Pressure/WallStress/BulkStress.update without time stepping: refreshes the derived
+ * fields from the current q (stress.py:289-362, 427-459, 600-622). */
+int gpf_update_closures(gpf_handle* h);
+
+/* ---- time stepping --------------------------------------------------------------------- */
+/* _pre_run (problem.py:412-443): step=0, residual=1, dt = CFL*dt_crit or dt_fixed, Ekin_old from q. */
+int gpf_pre_run(gpf_handle* h);
+/* n calls of Problem.update() (problem.py:509-586) enqueued back-to-back with no host
+ * round trip.  If honor_stop != 0 the steps become no-ops on the device once `converged`
+ * holds or step == max_it (the `while` of run(), problem.py:401); an invalid state
+ * (NaN / rho<0) always rolls back to the pre-step field and stops (problem.py:565-610).
+ * log (may be NULL): receives one gpf_scalars_t per executed step, at most log_capacity. */
+int gpf_step(gpf_handle* h, int64_t n, int honor_stop, gpf_scalars_t* log, int64_t log_capacity,
+             int64_t* n_executed);
+/* The reference-ordered, unfused stage pipeline (closures -> flux -> source -> axpy -> ghost),
+ * one kernel per reference function; same results as gpf_step(h,1,...).  Kept for
+ * cross-checking and for _finalize (problem.py:588-610). */
+int gpf_step_unfused(gpf_handle* h);
+/* scalars of the current state (mass, kinetic_energy, v_max, v_sound, dt_crit inputs) */
+int gpf_scalars(gpf_handle* h, gpf_scalars_t* out);
+int gpf_set_ekin_old(gpf_handle* h, double value);            /* kinetic_energy_old setter, tests/test_wave_decay.py:102 */
+int gpf_set_dt(gpf_handle* h, double dt);
+
+/* ---- slab decomposition (one process per GPU, x-slabs) ------------------------------------ */
+/* Device addresses of the four packed halo messages, each *count doubles long
+ * (3 components x padded row): send_lo/send_hi carry the first/last interior row of the field
+ * the current step has produced, recv_lo/recv_hi are scattered into rows ix=0 / ix=Nx+1 by
+ * gpf_step_commit.  Fixed for the life of the handle (usable as RCCL / torch.distributed buffers). */
+int gpf_halo_buffers(gpf_handle* h, void** send_lo, void** send_hi, void** recv_lo, void** recv_hi,
+                     size_t* count);
+/* Split step.  gpf_step_local: ghost-stage prepass + fused stencil update + local ghost rules +
+ * packing of the send rows; *totals = device address of this slab's 8-double record
+ * [sum Ekin, max v^2, max c^2 (NaN encoded as +inf), invalid flags, 0...].  Between the two
+ * calls the caller exchanges the halo messages and all-gathers the records of all slabs (rank
+ * order) into `gathered` (device, 8*nranks doubles).  gpf_step_commit scatters the received rows,
+ * reduces the records in rank order and advances dt / residual / step exactly as gpf_step does.
+ * Everything is enqueued on the handle's stream; neither call synchronises with the host. */
+int gpf_step_local(gpf_handle* h, int honor_stop, void** totals);
+int gpf_step_commit(gpf_handle* h, int honor_stop, const void* gathered, int nranks);
+/* Read back the run state after a batch of split steps (synchronises). */
+int gpf_state(gpf_handle* h, gpf_scalars_t* out);
+/* Topography across a periodic seam (halo kind 2): the rows the far side's first interior cell and
+ * its upwind neighbour see, needed to reproduce problem.py:683/690 exactly.
+ * side 0: edge ix=0, host = topo+Ls of global rows (Nx, Nx+1); side 1: edge ix=Nx+1, rows (1, 0).
+ * Layout double[2][4][Ny+2] (h, dh/dx, dh/dy, Ls per row). */
+int gpf_set_seam_topo(gpf_handle* h, int side, const double* host, size_t count);
+
+/* ---- stateless operators: GaPFlow/integrate.py ------------------------------------------ */
+/* predictor_corrector(q,p,tau,direction) -> flux_x, flux_y   (integrate.py:38-77) */
+int gpf_predictor_corrector(int nx, int ny, const double* q, const double* p, const double* tau,
+                            int direction, double* flux_x, double* flux_y);
+/* source(q,h,stress,stress_lower,stress_upper) -> out        (integrate.py:80-130); h = first 3 comps of the topography */
+int gpf_source(int nx, int ny, const double* q, const double* h, const double* stress,
+               const double* lower, const double* upper, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAPFLOW_HIP_H */

@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope='session')
+def hiplib():
+    """The built C-ABI library; GPU tests fail (not skip) when it is missing."""
+    from gapflow_amd import _lib
+    from gapflow_amd.build import build_library
+    build_library()
+    return _lib.require_device()
