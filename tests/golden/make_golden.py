@@ -191,7 +191,8 @@ CASES['journal1d_periodic'] = dict(yaml=open('/root/reference/examples/config/jo
 # tests/test_mass_conservation.py: 50x50 all-periodic journal, 50 steps
 CASES['journal2d_periodic50'] = dict(yaml=_testsim('test_mass_conservation.py'), snaps=[1, 50])
 # tests/test_flip_axes.py geometry, flipped (V-driven), 40x40 to stay small
-CASES['journal2d_flip40'] = dict(yaml=_testsim('test_flip_axes.py').replace('Nx: 100', 'Nx: 40').replace('Ny: 100', 'Ny: 40'),
+CASES['journal2d_flip40'] = dict(yaml=_testsim('test_flip_axes.py').replace('Nx: 100', 'Nx: 40').replace('Ny: 100', 'Ny: 40')
+                                 .replace('dx: 1.e-5', 'dx: 2.5e-5').replace('dy: 1.e-5', 'dy: 2.5e-5'),
                                  snaps=[1, 5], flip=True)
 # tests/test_wave_decay.py: cubic EOS, flat gap, fixed dt, sound wave n=2 seeded into jx
 CASES['wave_decay_cubic'] = dict(yaml=_testsim('test_wave_decay.py'), snaps=[1, 100], wave=2)
@@ -291,7 +292,7 @@ properties:
 """, snaps=[1, 30])
 
 
-def run_case(name, spec, use_ref):
+def run_case(name, spec, use_ref, perturb_seed=None):
     prob = OracleProblem.from_string(spec['yaml'])
     if spec.get('flip'):
         prob = OracleProblem.from_dict(_flipped(spec['yaml']))
@@ -304,6 +305,8 @@ def run_case(name, spec, use_ref):
         prob.q[1, 1:-1, :] = np.sin(kn * prob.x[1:-1, 1])[:, None]       # tests/test_wave_decay.py:127-129
         prob.kinetic_energy_old = prob.kinetic_energy
     res = {'q_init': prob.q.copy(), 'extra': prob.extra.copy(), 'topo': prob.topo.copy()}
+    if perturb_seed is not None:        # one-ulp relative noise on the initial field: conditioning probe
+        prob.q *= 1. + 2.2e-16 * np.random.default_rng(perturb_seed).standard_normal(prob.q.shape)
     hist = []
     for s in range(1, max(spec['snaps']) + 1):
         prob.update()
@@ -340,6 +343,21 @@ def step_fixtures():
                 else:
                     r, o = ref[k], own[k]
                 worst = max(worst, check(o, r, 1e-10, f'{name}:{k}'))
+        # Conditioning probe: how far does the *oracle itself* move when q_init is perturbed by one ulp?
+        # (stiff EOS: dp/drho ~ 1e8, so a 1e-16 relative change of rho moves j by ~1e-9 within a step).
+        # Stored per snapshot and component as |dq|_max / max|q_c|; the parity tests never ask for
+        # agreement tighter than this intrinsic noise.
+        sens_h = np.zeros(ref['history'].shape[1])
+        for seed in (11, 12, 13):
+            pert = run_case(name, spec, False, perturb_seed=seed)
+            for k in [k for k in ref if k.startswith('q_') and k != 'q_init']:
+                sc = np.array([np.abs(own[k][c]).max() or 1. for c in range(3)])
+                d = np.array([np.abs(pert[k][c] - own[k][c]).max() for c in range(3)]) / sc
+                ref['sens_' + k[2:]] = np.maximum(ref.get('sens_' + k[2:], 0.), d)
+            with np.errstate(all='ignore'):
+                dh = np.nanmax(np.abs(pert['history'] - own['history']) / np.maximum(np.abs(own['history']), 1e-300), axis=0)
+            sens_h = np.maximum(sens_h, np.nan_to_num(dh))
+        ref['sens_history'] = sens_h
         ref['yaml'] = np.array(spec['yaml'])
         ref['meta'] = np.array(repr({k: v for k, v in spec.items() if k != 'yaml'}))
         np.savez_compressed(os.path.join(HERE, f'step_{name}.npz'), **ref)

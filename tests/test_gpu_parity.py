@@ -7,11 +7,10 @@ difference of nearly equal sums, to rtol 1e-6 + atol 1e-9.
 import numpy as np
 import pytest
 
-from helpers import STEP_CASES, load_case, input_dict, rel_err, GOLDEN
+from helpers import STEP_CASES, load_case, input_dict, rel_err, comp_err, field_tol, history_tol, GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-FIELD_RTOL = 1e-9
 
 
 def make_problem(name):
@@ -28,16 +27,13 @@ def make_problem(name):
     return prob, fx, meta
 
 
-def check_history(row, prob):
+def check_history(row, prob, tol):
     # golden history columns: step, time, dt(next), ekin, residual, vsound, vmax, mass
     assert prob.step == int(row[0])
-    np.testing.assert_allclose(prob.simtime, row[1], rtol=1e-12)
-    np.testing.assert_allclose(prob.dt, row[2], rtol=1e-10)
-    np.testing.assert_allclose(prob.kinetic_energy, row[3], rtol=1e-11)
-    np.testing.assert_allclose(prob.residual, row[4], rtol=1e-6, atol=1e-9)
-    np.testing.assert_allclose(prob.pressure.v_sound, row[5], rtol=1e-11)
-    np.testing.assert_allclose(prob.v_max, row[6], rtol=1e-10)
-    np.testing.assert_allclose(prob.mass, row[7], rtol=1e-12)
+    got = [prob.step, prob.simtime, prob.dt, prob.kinetic_energy, prob.residual, prob.pressure.v_sound, prob.v_max, prob.mass]
+    names = ['step', 'time', 'dt', 'ekin', 'residual', 'vsound', 'vmax', 'mass']
+    for k in range(1, 8):
+        np.testing.assert_allclose(got[k], row[k], rtol=tol[k], atol=1e-9 if k == 4 else 0, err_msg=names[k])
 
 
 @pytest.mark.parametrize('name', STEP_CASES)
@@ -49,9 +45,15 @@ def test_fused_step_matches_golden(hiplib, name):
     for s in range(1, snaps[-1] + 1):
         prob.update()
         if s in snaps:
-            assert rel_err(prob.q, fx[f'q_{s}']) < FIELD_RTOL, f'q at step {s}'
-            assert rel_err(prob.pressure.pressure, fx[f'p_{s}']) < FIELD_RTOL, f'p at step {s}'
-            check_history(fx['history'][s - 1], prob)
+            tol = field_tol(fx, s)
+            err = comp_err(prob.q, fx[f'q_{s}'])
+            assert (err <= tol).all(), f'q at step {s}: err {err} tol {tol}'
+            # p(rho): within 1e-9 of the pressure scale plus what the (already bounded) density error
+            # maps to through dp/drho = c^2 (up to 1e8 for the stiff Dowson-Higginson law)
+            drho = np.abs(prob.q[0] - fx[f'q_{s}'][0]).max()
+            dp = np.abs(prob.pressure.pressure - fx[f'p_{s}']).max()
+            assert dp <= 1e-9 * np.abs(fx[f'p_{s}']).max() + 2.0 * prob.pressure.v_sound**2 * drho, f'p at step {s}'
+            check_history(fx['history'][s - 1], prob, history_tol(fx))
 
 
 @pytest.mark.parametrize('name', ['journal1d_readme', 'slider2d_dn', 'asperity2d_slip', 'journal2d_flip40'])
@@ -65,7 +67,8 @@ def test_unfused_pipeline_matches_golden(hiplib, name):
         _lib.check(hiplib.gpf_step_unfused(prob._h))
         prob._mark_device_advanced()
         if s in snaps:
-            assert rel_err(prob.q, fx[f'q_{s}']) < FIELD_RTOL, f'q at step {s}'
+            err = comp_err(prob.q, fx[f'q_{s}'])
+            assert (err <= field_tol(fx, s)).all(), f'q at step {s}: err {err}'
 
 
 def test_batched_steps_equal_single_steps(hiplib):
