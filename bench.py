@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fused MacCormack step on the 4096 x 4096 fp64 journal-bearing grid.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one full MacCormack time step (both stages, averaging, ghost cells, per-step
+scalars and the device-side dt/residual update) of BASELINE.json configs[2]: 2-D journal bearing,
+4096 x 4096, Dowson-Higginson EOS, all-periodic, adaptive CFL 0.5.  The field is
+resident in HBM before the timed region; `value` = Nx*Ny*K / t in Mcell-updates/s over all ranks.
+
+For N > 1 the driver launches this file under torch.distributed.run, one rank per GPU; the grid
+is cut into N x-slabs (strong scaling: the 4096^2 problem is fixed) with one halo-row exchange
+and one 64-byte all-gather per step over RCCL.
+
+Extra objects on the JSON line:
+  roofline     -- dominant kernel (k_step): algorithmic bytes (72 B x cells per launch) / its mean
+                  launch duration from HIP events on the launch stream, against 8 TB/s HBM3E.
+  cpu_baseline -- the NumPy oracle (oracle/, a restatement of the reference's CPU path) timed on
+                  this host on a bounded sample of the same workload.
+"""
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_GRID = int(os.environ.get('GPF_BENCH_N', 4096))
+BYTES_PER_CELL = 72.0           # read q (24) + read h, dh/dx, dh/dy (24) + write q (24), SURVEY.md 8d
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOAD_YAML = """
+options:
+    output: data/bench
+    write_freq: 1000000
+    silent: True
+grid:
+    dx: 1.e-5
+    dy: 1.e-5
+    Nx: {N}
+    Ny: {N}
+    xE: ['P', 'P', 'P']
+    xW: ['P', 'P', 'P']
+    yS: ['P', 'P', 'P']
+    yN: ['P', 'P', 'P']
+geometry:
+    type: journal
+    CR: 1.e-2
+    eps: 0.7
+    U: 0.1
+    V: 0.
+numerics:
+    CFL: 0.5
+    adaptive: 1
+    tol: 1e-12
+    dt: 1e-10
+    max_it: 100000000
+properties:
+    shear: 0.0794
+    bulk: 0.
+    EOS: DH
+    P0: 101325.
+    rho0: 877.7007
+    C1: 3.5e10
+    C2: 1.23
+"""
+
+
+def cpu_baseline(sample_n=1024, steps=4):
+    """The oracle on a bounded sample: same YAML with Nx=Ny=sample_n, `steps` timed steps after one warm-up."""
+    from oracle.problem import OracleProblem
+    with contextlib.redirect_stdout(sys.stderr):
+        p = OracleProblem.from_string(WORKLOAD_YAML.format(N=sample_n))
+        p._pre_run()
+        p.update()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            p.update()
+        dt = time.perf_counter() - t0
+    return {"value": sample_n * sample_n * steps / dt / 1e6, "unit": "Mcell-updates/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/ (NumPy restatement of the reference CPU path, single-threaded ufuncs; host has "
+                      f"{os.cpu_count()} cores), same YAML at {sample_n}x{sample_n}, {steps} steps, {dt:.1f} s"}
+
+
+def run_single(args):
+    import ctypes as C
+    from gapflow_amd import Problem, _lib
+    with contextlib.redirect_stdout(sys.stderr):
+        prob = Problem.from_string(WORKLOAD_YAML.format(N=N_GRID))
+        prob._pre_run()
+        lib = prob._lib
+        if args.warmup > 0:
+            prob._advance(args.warmup, honor_stop=False)
+        # --- timed region: K steps enqueued back to back, one host sync at the end ---
+        nexec = C.c_int64(0)
+        _lib.check(lib.gpf_scalars(prob._h, C.byref(_lib.GpfScalars())))      # drains the stream
+        t0 = time.perf_counter()
+        done = 0
+        while done < args.steps:
+            n = min(4096, args.steps - done)
+            _lib.check(lib.gpf_step(prob._h, n, 0, None, 0, C.byref(nexec)))    # returns after a stream sync
+            done += n
+        t1 = time.perf_counter()
+        assert int(nexec.value) == args.warmup + args.steps, "steps were skipped inside the timed region"
+        # --- kernel time of the dominant kernel, HIP events on the launch stream ---
+        kt, tt = C.c_double(0), C.c_double(0)
+        nk = min(max(args.steps, 1), 200)
+        _lib.check(lib.gpf_step_timed(prob._h, nk, C.byref(kt), C.byref(tt)))
+        sc = prob._scalars()
+        assert sc.invalid == 0 and sc.ekin == sc.ekin, "state went invalid during the benchmark"
+    wall = t1 - t0
+    cells = N_GRID * N_GRID
+    kernel_s = kt.value / nk / 1e3
+    achieved = BYTES_PER_CELL * cells / kernel_s / 1e9
+    out = {
+        "metric": "Mcell-updates/s (fp64), 4096^2 grid", "value": cells * args.steps / wall / 1e6,
+        "unit": "Mcell-updates/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"2D journal bearing {N_GRID}x{N_GRID}, fixed DH EOS, all-periodic, adaptive CFL 0.5 "
+                               "(BASELINE.json configs[2])", "slabs": 1},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_step<DH>",
+                     "kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_launch": BYTES_PER_CELL * cells,
+                     "all_kernels_ms_per_step": tt.value / nk},
+    }
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline()
+    return out
+
+
+def run_slabs(args, rank, world):
+    import torch
+    import torch.distributed as dist
+    from gapflow_amd.slab import SlabProblem
+    local = int(os.environ.get('LOCAL_RANK', rank))
+    torch.cuda.set_device(local)
+    dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    with contextlib.redirect_stdout(sys.stderr):
+        prob = SlabProblem.from_string(WORKLOAD_YAML.format(N=N_GRID), device=local)
+        prob.pre_run()
+        prob.advance(args.warmup)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        prob.advance(args.steps)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        st = prob.state()
+        assert st.step == args.warmup + args.steps and st.invalid == 0
+    wall = torch.tensor([t1 - t0], dtype=torch.float64, device='cuda')
+    dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+    wall = float(wall.item())
+    cells = N_GRID * N_GRID
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "Mcell-updates/s (fp64), 4096^2 grid", "value": cells * args.steps / wall / 1e6,
+            "unit": "Mcell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"2D journal bearing {N_GRID}x{N_GRID}, fixed DH EOS, all-periodic, adaptive CFL 0.5 "
+                                   "(BASELINE.json configs[2])", "slabs": world,
+                       "parallelism": f"{world} x-slabs, RCCL halo ring + 64-B all-gather per step"},
+            "roofline": {"bound": "hbm", "achieved": BYTES_PER_CELL * cells * args.steps / wall / 1e9 / world,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": BYTES_PER_CELL * cells * args.steps / wall / 1e9 / world / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "whole step per GPU (wall clock, incl. exchange)"},
+        }
+    dist.barrier()
+    dist.destroy_process_group()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    args = ap.parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if args.gpus > 1 or world > 1:
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} ranks: launch with "
+                             f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...")
+        out = run_slabs(args, rank, world)
+    else:
+        out = run_single(args)
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == '__main__':
+    main()

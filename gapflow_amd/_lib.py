@@ -56,6 +56,7 @@ SIGNATURES = {
     'gpf_pre_run': (C.c_int, [C.c_void_p]),
     'gpf_step': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(GpfScalars), C.c_int64, C.POINTER(C.c_int64)]),
     'gpf_step_unfused': (C.c_int, [C.c_void_p]),
+    'gpf_step_timed': (C.c_int, [C.c_void_p, C.c_int64, _DP, _DP]),
     'gpf_scalars': (C.c_int, [C.c_void_p, C.POINTER(GpfScalars)]),
     'gpf_set_ekin_old': (C.c_int, [C.c_void_p, C.c_double]),
     'gpf_set_dt': (C.c_int, [C.c_void_p, C.c_double]),

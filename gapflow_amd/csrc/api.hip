@@ -487,7 +487,8 @@ extern "C" int gpf_pre_run(gpf_handle* h) {
 // ---------------------------------------------------------------------------------------------
 // the fused step
 // ---------------------------------------------------------------------------------------------
-static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, double* slab_out) {
+static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, double* slab_out,
+                        hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     const Layout& L = h->L;
     StepArgs a;
     a.qa = h->q[0]; a.qb = h->q[1]; a.topo = h->topo; a.Ls = h->Ls;
@@ -514,10 +515,14 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     EOS_DISPATCH(h->cfg.eos, {
         if (h->Ls) {
             hipLaunchKernelGGL((k_ghost_stage1<EOS_, true>), ggrid, dim3(256), 0, h->stream, g, h->P);
+            if (ev0) hipEventRecord(ev0, h->stream);
             hipLaunchKernelGGL((k_step<EOS_, true>), sgrid, dim3(256), 0, h->stream, a, h->P);
+            if (ev1) hipEventRecord(ev1, h->stream);
         } else {
             hipLaunchKernelGGL((k_ghost_stage1<EOS_, false>), ggrid, dim3(256), 0, h->stream, g, h->P);
+            if (ev0) hipEventRecord(ev0, h->stream);
             hipLaunchKernelGGL((k_step<EOS_, false>), sgrid, dim3(256), 0, h->stream, a, h->P);
+            if (ev1) hipEventRecord(ev1, h->stream);
         }
         hipLaunchKernelGGL((k_finish<EOS_>), dim3(1), dim3(1024), 0, h->stream, f, h->P);
     });
@@ -554,6 +559,35 @@ extern "C" int gpf_step(gpf_handle* h, int64_t n, int honor_stop, gpf_scalars_t*
     }
     if (n_executed) *n_executed = h->host_step;
     return GPF_OK;
+}
+
+// n steps with a HIP event pair around every launch of the fused step kernel (on the handle's
+// stream): *kernel_ms = summed duration of the n k_step launches, *total_ms = first event to last.
+extern "C" int gpf_step_timed(gpf_handle* h, int64_t n, double* kernel_ms, double* total_ms) {
+    if (!h || !kernel_ms || !total_ms) return fail(GPF_ERR_INVALID, "gpf_step_timed: null argument");
+    if (!h->pre_run_done) return fail(GPF_ERR_STATE, "gpf_step_timed: call gpf_pre_run first");
+    if (n < 1 || n > h->log_cap) return fail(GPF_ERR_INVALID, "gpf_step_timed: 1 <= n <= 4096");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    std::vector<hipEvent_t> ev(2 * n + 2);
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventRecord(ev[2 * n], h->stream));
+    int rc = GPF_OK;
+    for (int64_t i = 0; i < n && rc == GPF_OK; ++i) rc = enqueue_step(h, 0, h->host_step, nullptr, ev[2 * i], ev[2 * i + 1]);
+    HIP_TRY(hipEventRecord(ev[2 * n + 1], h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    double sum = 0.0;
+    float ms = 0.f;
+    for (int64_t i = 0; i < n; ++i) {
+        HIP_TRY(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+        sum += ms;
+    }
+    HIP_TRY(hipEventElapsedTime(&ms, ev[2 * n], ev[2 * n + 1]));
+    *kernel_ms = sum; *total_ms = ms;
+    for (auto& e : ev) hipEventDestroy(e);
+    StepState s;
+    GPF_TRY(read_state(h, s));
+    h->host_step = s.step;
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------

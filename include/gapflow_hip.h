@@ -130,6 +130,10 @@ int gpf_pre_run(gpf_handle* h);
  * log (may be NULL): receives one gpf_scalars_t per executed step, at most log_capacity. */
 int gpf_step(gpf_handle* h, int64_t n, int honor_stop, gpf_scalars_t* log, int64_t log_capacity,
              int64_t* n_executed);
+/* Measurement aid: n updates with a HIP event pair around each launch of the fused step kernel
+ * (recorded on the handle's stream).  *kernel_ms = sum of the n kernel durations, *total_ms =
+ * elapsed device time of the whole sequence (prepass + step + finish kernels). */
+int gpf_step_timed(gpf_handle* h, int64_t n, double* kernel_ms, double* total_ms);
 /* The reference-ordered, unfused stage pipeline (closures -> flux -> source -> axpy -> ghost),
  * one kernel per reference function; same results as gpf_step(h,1,...).  Kept for
  * cross-checking and for _finalize (problem.py:588-610). */
