@@ -52,7 +52,7 @@ struct gpf_handle {
     double* halo = nullptr;                 // send_lo, send_hi, recv_lo, recv_hi: each [3][pitch]; then the 8-double slab record
     StepState* st = nullptr;
     Partial* partials = nullptr;
-    int npartials = 0, nstrips = 0, nchunks = 0, rows_per_chunk = 0;
+    int npartials = 0, nstrips = 0, nchunks = 0, rows_per_chunk = 0, nghost_blocks = 0;
     ScalarPartial* spart = nullptr;         // k_scalars block records (+ 4 totals at the end)
     int nspart = 0;
     LogEntry* log = nullptr;
@@ -235,8 +235,9 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
     HIP_TRY_C(hipMemset(h->g1, 0, g1n * sizeof(double)));
     HIP_TRY_C(hipMalloc(&h->st, sizeof(StepState)));
     HIP_TRY_C(hipMemset(h->st, 0, sizeof(StepState)));
-    HIP_TRY_C(hipMalloc(&h->partials, (size_t)h->npartials * sizeof(Partial)));
-    HIP_TRY_C(hipMemset(h->partials, 0, (size_t)h->npartials * sizeof(Partial)));
+    h->nghost_blocks = std::max(1, std::min(64, (2 * (L.Ny + 2) + 2 * L.Nx + 255) / 256));
+    HIP_TRY_C(hipMalloc(&h->partials, (size_t)(h->npartials + h->nghost_blocks) * sizeof(Partial)));
+    HIP_TRY_C(hipMemset(h->partials, 0, (size_t)(h->npartials + h->nghost_blocks) * sizeof(Partial)));
     h->nspart = 1024;
     HIP_TRY_C(hipMalloc(&h->spart, (size_t)(h->nspart + 8) * sizeof(ScalarPartial)));
     HIP_TRY_C(hipMemset(h->spart, 0, (size_t)(h->nspart + 8) * sizeof(ScalarPartial)));
@@ -506,8 +507,10 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     }
     g.g1x = h->g1; g.g1y = h->g1 + 3 * L.pitch; g.st = h->st; g.L = L; g.E = h->E; g.honor_stop = honor_stop;
     FinishArgs f;
-    f.qa = h->q[0]; f.qb = h->q[1]; f.partials = h->partials; f.npartials = h->npartials; f.st = h->st;
-    f.L = L; f.E = h->E;
+    f.partials = h->partials; f.npartials = h->npartials + h->nghost_blocks; f.st = h->st;
+    GhostFillArgs gf;
+    gf.qa = h->q[0]; gf.qb = h->q[1]; gf.st = h->st; gf.partials = h->partials + h->npartials;
+    gf.L = L; gf.E = h->E; gf.honor_stop = honor_stop;
     f.log = h->log; f.log_base = log_base; f.log_cap = h->log_cap; f.out = slab_out; f.honor_stop = honor_stop;
 
     const int gmax = std::max(L.Nx, L.Ny);
@@ -524,8 +527,9 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
             hipLaunchKernelGGL((k_step<EOS_, false>), sgrid, dim3(256), 0, h->stream, a, h->P);
             if (ev1) hipEventRecord(ev1, h->stream);
         }
-        hipLaunchKernelGGL((k_finish<EOS_>), dim3(1), dim3(1024), 0, h->stream, f, h->P);
+            hipLaunchKernelGGL((k_ghost_fill<EOS_>), dim3(h->nghost_blocks), dim3(256), 0, h->stream, gf, h->P);
     });
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, h->stream, f);
     HIP_TRY(hipGetLastError());
     return GPF_OK;
 }

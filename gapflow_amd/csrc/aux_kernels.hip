@@ -185,83 +185,94 @@ __device__ inline void commit_step(StepState* st, double ekin, double v2, double
 }
 
 // ---------------------------------------------------------------------------------------------
-// finish of the fused step: ghost rules on the new field, scalars over interior partials +
-// ghost cells, commit.  One block (the edge work is O(N), the stencil is O(N^2)).
+// ghost cells of the field k_step has just written (problem.py:576 -> 676-768), in parallel:
+// one thread per ghost cell of the two ghost rows / two ghost columns; the four corners are
+// rule_y(rule_x(.)) exactly as the reference's x-then-y order produces them.  Each block also
+// leaves one reduction record covering the ghost cells it wrote (the reference's Ekin / v_max /
+// v_sound run over ghost cells too, problem.py:342-347).
+// ---------------------------------------------------------------------------------------------
+struct GhostFillArgs {
+    double* qa; double* qb;
+    const StepState* st;
+    Partial* partials;      // gridDim.x records, behind the step kernel's
+    Layout L; Edges E;
+    int honor_stop;
+};
+
+template <int EOS>
+__global__ __launch_bounds__(256) void k_ghost_fill(const GhostFillArgs a, const Phys P) {
+    __shared__ Acc sm[4];
+    const StepState* st = a.st;
+    if (st->invalid != 0 || (a.honor_stop && (st->converged || st->step >= st->max_it))) return;
+    const Layout& L = a.L;
+    double* q = st->parity ? a.qa : a.qb;      // the buffer k_step has just written
+    Acc acc; acc.zero();
+    auto put = [&](int ix, int iy, const double v[3], double w) {
+        const long long o = L.at(ix, iy);
+        q[o] = v[0]; q[o + L.plane] = v[1]; q[o + 2 * L.plane] = v[2];
+        acc.cell<EOS>(v[0], v[1], v[2], 0.0, P, w);
+    };
+    // work items: [0, 2*(Ny+2)) ghost rows incl. corners, then [.., + 2*Nx) ghost columns of interior rows
+    const int nrow = 2 * (L.Ny + 2), ncol = 2 * L.Nx;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nrow + ncol; t += gridDim.x * blockDim.x) {
+        double v[3];
+        if (t < nrow) {
+            const int e = t / (L.Ny + 2), iy = t % (L.Ny + 2);
+            if (a.E.halo[e]) continue;                        // filled by the neighbour exchange
+            const int ix = e == 0 ? 0 : L.Nx + 1;
+            if (iy >= 1 && iy <= L.Ny) {
+                for (int c = 0; c < 3; ++c) v[c] = ghost_x(q, L, a.E, e, c, iy);
+            } else {
+                // corner: the y rule applied to the ghost-row value of the source column
+                const int ey = iy == 0 ? 2 : 3;
+                const int r0 = a.E.rule[ey][0];
+                const int src = (r0 == BC_P) ? (ey == 2 ? L.Ny : 1) : (ey == 2 ? 1 : L.Ny);
+                for (int c = 0; c < 3; ++c) {
+                    const double gx = ghost_x(q, L, a.E, e, c, src);
+                    v[c] = a.E.rule[ey][c] == BC_D ? 2.0 * a.E.value[ey] - gx : gx;
+                }
+            }
+            put(ix, iy, v, 1.0);
+        } else {
+            const int u = t - nrow;
+            const int e = 2 + u / L.Nx, ix = 1 + u % L.Nx;
+            for (int c = 0; c < 3; ++c) v[c] = ghost_y(q, L, a.E, e, c, ix);
+            // a row next to a periodic slab seam also stands in for the far slab's ghost row
+            const double w = 1.0 + ((ix == 1 && a.E.halo[0] == 2) ? 1.0 : 0.0) + ((ix == L.Nx && a.E.halo[1] == 2) ? 1.0 : 0.0);
+            put(ix, e == 2 ? 0 : L.Ny + 1, v, w);
+        }
+    }
+    acc = block_reduce(acc, sm);
+    if (threadIdx.x == 0) {
+        Partial p;
+        p.ekin = acc.ekin; p.vmax2 = acc.v2; p.c2max = acc.c2; p.flags = (double)acc.flags;
+        a.partials[blockIdx.x] = p;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// finish of the fused step: reduce the per-wave records of k_step (which already cover the ghost
+// cells it wrote) and commit.  One small block.
 // ---------------------------------------------------------------------------------------------
 struct FinishArgs {
-    double* qa; double* qb;
     const Partial* partials; int npartials;
     StepState* st;
-    Layout L; Edges E;
     LogEntry* log; long long log_base, log_cap;
     double* out;            // if non-null: slab mode, write the 8-double local record here instead of committing
     int honor_stop;
 };
 
-template <int EOS>
-__global__ __launch_bounds__(1024) void k_finish(const FinishArgs a, const Phys P) {
-    __shared__ Acc sm[16];
+__global__ __launch_bounds__(256) void k_finish(const FinishArgs a) {
+    __shared__ Acc sm[4];
     StepState* st = a.st;
     if (st->invalid != 0 || (a.honor_stop && (st->converged || st->step >= st->max_it))) return;
-    const Layout& L = a.L;
-    double* q = st->parity ? a.qa : a.qb;      // the buffer k_step has just written
-    const int T = blockDim.x, t = threadIdx.x;
-
-    // 1. x ghost rows over interior columns, y ghost columns over interior rows (independent)
-    for (int iy = 1 + t; iy <= L.Ny; iy += T)
-        for (int e = 0; e < 2; ++e) {
-            if (a.E.halo[e]) continue;
-            const int ix = e == 0 ? 0 : L.Nx + 1;
-            for (int c = 0; c < 3; ++c) q[c * L.plane + L.at(ix, iy)] = ghost_x(q, L, a.E, e, c, iy);
-        }
-    for (int ix = 1 + t; ix <= L.Nx; ix += T)
-        for (int e = 2; e < 4; ++e) {
-            const int iy = e == 2 ? 0 : L.Ny + 1;
-            for (int c = 0; c < 3; ++c) q[c * L.plane + L.at(ix, iy)] = ghost_y(q, L, a.E, e, c, ix);
-        }
-    __threadfence_block();
-    __syncthreads();
-    // 2. corners: y rule applied to the freshly written ghost rows
-    if (t < 12) {
-        const int k = t / 3, c = t % 3;
-        const int ex = k & 1, ey = 2 + (k >> 1);
-        if (!a.E.halo[ex]) {
-            const int ix = ex == 0 ? 0 : L.Nx + 1, iy = ey == 2 ? 0 : L.Ny + 1;
-            q[c * L.plane + L.at(ix, iy)] = ghost_y(q, L, a.E, ey, c, ix);
-        }
-    }
-    __threadfence_block();
-    __syncthreads();
-
-    // 3. scalars: ghost cells here, interior from the step kernel's per-wave records
     Acc acc; acc.zero();
-    const double* topo_dummy = nullptr; (void)topo_dummy;
-    auto add = [&](int ix, int iy, double w) {
-        const long long o = L.at(ix, iy);
-        acc.cell<EOS>(q[o], q[o + L.plane], q[o + 2 * L.plane], 0.0, P, w);
-    };
-    for (int iy = t; iy <= L.Ny + 1; iy += T) {
-        if (!a.E.halo[0]) add(0, iy, 1.0);
-        if (!a.E.halo[1]) add(L.Nx + 1, iy, 1.0);
-    }
-    for (int ix = 1 + t; ix <= L.Nx; ix += T) {
-        // a periodic seam: the interior row next to it doubles as the far slab's ghost row, which that
-        // slab cannot sum before the exchange -- count it twice here instead
-        const double w = 1.0 + (ix == 1 && a.E.halo[0] == 2 ? 1.0 : 0.0) + (ix == L.Nx && a.E.halo[1] == 2 ? 1.0 : 0.0);
-        add(ix, 0, w);
-        add(ix, L.Ny + 1, w);
-    }
-    for (int e = 0; e < 2; ++e)
-        if (a.E.halo[e] == 2) {
-            const int ix = e == 0 ? 1 : L.Nx;
-            for (int iy = 1 + t; iy <= L.Ny; iy += T) add(ix, iy, 1.0);
-        }
-    for (int i = t; i < a.npartials; i += T) {
+    for (int i = threadIdx.x; i < a.npartials; i += blockDim.x) {
         const Partial p = a.partials[i];
         acc.ekin += p.ekin; acc.v2 = nanmax(acc.v2, p.vmax2); acc.c2 = nanmax(acc.c2, p.c2max); acc.flags |= (int)p.flags;
     }
     acc = block_reduce(acc, sm);
-    if (t == 0) {
+    if (threadIdx.x == 0) {
         if (a.out) {
             // slab mode: NaN maxima travel as +inf so that any reduction order keeps them
             const double inf = __builtin_inf();

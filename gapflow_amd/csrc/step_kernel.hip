@@ -168,7 +168,10 @@ __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, con
                     qout[o + L.plane] = o1;
                     qout[o + 2 * L.plane] = o2;
                     const double v2 = (o1 * o1 + o2 * o2) / o0;
-                    r_ekin += v2 * 0.5;
+                    // a row next to a periodic slab seam also stands in for the far slab's ghost row
+                    const double w = 1.0 + ((ixo == 1 && a.E.halo[0] == 2) ? 1.0 : 0.0) +
+                                     ((ixo == L.Nx && a.E.halo[1] == 2) ? 1.0 : 0.0);
+                    r_ekin += w * (v2 * 0.5);
                     r_v2 = nanmax(r_v2, v2);
                     double c2 = eos_c2<EOS>(o0, P);
                     c2 = (c2 < 0.0) ? __builtin_nan("") : c2;
