@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'lib', 'libgapflow_hip.so')
+LIB_PATH = os.environ.get('GPF_LIB_PATH', os.path.join(HERE, 'lib', 'libgapflow_hip.so'))
 
 EOS_IDS = {'DH': 0, 'PL': 1, 'vdW': 2, 'MT': 3, 'cubic': 4, 'BWR': 5, 'Bayada': 6}
 EOS_KEYS = {'DH': ['rho0', 'P0', 'C1', 'C2'], 'PL': ['rho0', 'P0', 'alpha'], 'vdW': ['M', 'T', 'a', 'b'],

@@ -64,19 +64,23 @@ struct gpf_handle {
     double* work = nullptr;                 // fx(3) fy(3) src(3)
     bool has_q = false, has_topo = false, pre_run_done = false;
     long long host_step = 0;                // step count at the last sync
+    long long next_step = 0;                // index of the next step to be enqueued (== device step unless halted)
+    bool plan_valid = false;                // rows_per_chunk / nchunks fitted to the step kernel's residency
+    int max_chunks = 0;
 };
 
 // ---------------------------------------------------------------------------------------------
 static void make_phys(const gpf_config& c, Phys& P) {
     std::memset(&P, 0, sizeof(P));
     P.U = c.U; P.V = c.V; P.eta = c.eta; P.zeta = c.zeta;
+    P.v1 = c.zeta + (4.0 / 3.0) * c.eta; P.v2 = c.zeta - (2.0 / 3.0) * c.eta;      // viscous.py:82-83
     P.inv_dx = 1.0 / c.dx; P.inv_dy = 1.0 / c.dy;
     P.eos = c.eos; P.piezo = c.piezo;
     const double* e = c.eos_par;
     switch (c.eos) {
     case GPF_EOS_DH:     // rho0, P0, C1, C2
         P.e[0] = e[0]; P.e[1] = e[1]; P.e[2] = e[2]; P.e[3] = e[3];
-        P.e[4] = 0.99 * e[3] * e[0]; P.e[5] = 1.0 / e[0]; P.e[6] = e[2] * e[0] * (e[3] - 1.0);
+        P.e[4] = 0.99 * e[3] * e[0]; P.e[5] = 1.0 / e[0]; P.e[6] = e[2] * e[0] * (e[3] - 1.0); P.e[7] = e[3] * e[0];
         break;
     case GPF_EOS_PL:     // rho0, P0, alpha
         P.e[0] = e[0]; P.e[1] = e[1]; P.e[2] = e[2]; P.e[3] = 1.0 / (1.0 - 0.5 * e[2]);
@@ -139,15 +143,15 @@ static int blocks_for(long long n, int bs = 256, int cap = 4096) {
     return (int)std::max<long long>(1, std::min<long long>(b, cap));
 }
 
-#define EOS_DISPATCH(eos, CALL)                                                                         \
+#define EOS_DISPATCH(eos, ...)                                                                          \
     switch (eos) {                                                                                      \
-    case GPF_EOS_DH: { constexpr int EOS_ = EOS_DH; CALL; } break;                                     \
-    case GPF_EOS_PL: { constexpr int EOS_ = EOS_PL; CALL; } break;                                     \
-    case GPF_EOS_VDW: { constexpr int EOS_ = EOS_VDW; CALL; } break;                                   \
-    case GPF_EOS_MT: { constexpr int EOS_ = EOS_MT; CALL; } break;                                     \
-    case GPF_EOS_CUBIC: { constexpr int EOS_ = EOS_CUBIC; CALL; } break;                               \
-    case GPF_EOS_BWR: { constexpr int EOS_ = EOS_BWR; CALL; } break;                                   \
-    default: { constexpr int EOS_ = EOS_BAYADA; CALL; } break;                                         \
+    case GPF_EOS_DH: { constexpr int EOS_ = EOS_DH; __VA_ARGS__; } break;                              \
+    case GPF_EOS_PL: { constexpr int EOS_ = EOS_PL; __VA_ARGS__; } break;                              \
+    case GPF_EOS_VDW: { constexpr int EOS_ = EOS_VDW; __VA_ARGS__; } break;                            \
+    case GPF_EOS_MT: { constexpr int EOS_ = EOS_MT; __VA_ARGS__; } break;                              \
+    case GPF_EOS_CUBIC: { constexpr int EOS_ = EOS_CUBIC; __VA_ARGS__; } break;                        \
+    case GPF_EOS_BWR: { constexpr int EOS_ = EOS_BWR; __VA_ARGS__; } break;                            \
+    default: { constexpr int EOS_ = EOS_BAYADA; __VA_ARGS__; } break;                                  \
     }
 
 // ---------------------------------------------------------------------------------------------
@@ -203,18 +207,11 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
     h->E.halo[0] = cfg->halo_lo; h->E.halo[1] = cfg->halo_hi;
     make_phys(*cfg, h->P);
 
-    // strips / chunks of the fused step
+    // strips of the fused step; the split of the rows into chunks is fitted to the kernel's residency
+    // on first use (plan_step), at most max_chunks of >= 8 rows
     h->nstrips = (L.Ny + STRIP - 1) / STRIP;
-    int rows = 0;
-    if (const char* s = std::getenv("GPF_ROWS_PER_CHUNK")) rows = std::atoi(s);
-    if (rows <= 0) {
-        int want_chunks = std::max(1, (4096 + h->nstrips - 1) / h->nstrips);
-        want_chunks = std::min(want_chunks, std::max(1, L.Nx / 16));
-        rows = (L.Nx + want_chunks - 1) / want_chunks;
-    }
-    h->rows_per_chunk = std::max(1, std::min(rows, L.Nx));
-    h->nchunks = (L.Nx + h->rows_per_chunk - 1) / h->rows_per_chunk;
-    h->npartials = h->nstrips * h->nchunks;
+    h->max_chunks = std::max(1, (L.Nx + 7) / 8);
+    h->npartials = h->nstrips * h->max_chunks;
 
     const size_t plane_b = (size_t)L.plane * sizeof(double);
     auto cleanup = [&](int code) { gpf_destroy(h); return code; };
@@ -314,7 +311,7 @@ extern "C" int gpf_upload(gpf_handle* h, int field, const double* host, size_t c
         bool nz = false;
         for (size_t i = 0; i < count && !nz; ++i) nz = host[i] != 0.0;
         if (!nz && !h->Ls) return GPF_OK;      // Ls == 0 everywhere: the HAS_LS=false kernels apply
-        if (!h->Ls) HIP_TRY(hipMalloc(&h->Ls, (size_t)L.plane * sizeof(double)));
+        if (!h->Ls) { HIP_TRY(hipMalloc(&h->Ls, (size_t)L.plane * sizeof(double))); h->plan_valid = false; }
         HIP_TRY(hipMemsetAsync(h->Ls, 0, (size_t)L.plane * sizeof(double), h->stream));
         dst = h->Ls;
     }
@@ -481,16 +478,62 @@ extern "C" int gpf_pre_run(gpf_handle* h) {
     s.dt = c.adaptive ? c.CFL * dt_crit : c.dt_fixed;
     GPF_TRY(write_state(h, s));
     h->pre_run_done = true;
-    h->host_step = 0;
+    h->host_step = 0; h->next_step = 0;
     return GPF_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
 // the fused step
 // ---------------------------------------------------------------------------------------------
+typedef void (*step_kernel_t)(const StepArgs, const Phys);
+
+static step_kernel_t step_kernel(int eos, bool has_ls, bool piezo, int D) {
+    step_kernel_t k = nullptr;
+    EOS_DISPATCH(eos, {
+        if (piezo) {
+            if (has_ls) k = D > 0 ? k_step<EOS_, true, true, 1> : k_step<EOS_, true, true, -1>;
+            else k = D > 0 ? k_step<EOS_, false, true, 1> : k_step<EOS_, false, true, -1>;
+        } else {
+            if (has_ls) k = D > 0 ? k_step<EOS_, true, false, 1> : k_step<EOS_, true, false, -1>;
+            else k = D > 0 ? k_step<EOS_, false, false, 1> : k_step<EOS_, false, false, -1>;
+        }
+    });
+    return k;
+}
+
+// One wave marches over `rows_per_chunk` rows of one strip.  The chunks are sized so that the whole
+// grid is resident at once (a single round of waves, no tail) when the problem is big enough.
+static int plan_step(gpf_handle* h) {
+    if (h->plan_valid) return GPF_OK;
+    const Layout& L = h->L;
+    int rows = 0;
+    if (const char* s = std::getenv("GPF_ROWS_PER_CHUNK")) rows = std::atoi(s);
+    if (rows <= 0) {
+        int per_cu = 0, ncu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)step_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, 1), 256, 0));
+        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->cfg.device));
+        const int blocks_per_chunk = (h->nstrips + 3) / 4;
+        const int resident = std::max(1, per_cu * ncu);
+        const int want_chunks = std::max(1, resident / blocks_per_chunk);
+        rows = (L.Nx + want_chunks - 1) / want_chunks;
+    }
+    rows = std::max(8, std::min(rows, L.Nx));
+    if (rows > L.Nx) rows = L.Nx;
+    h->rows_per_chunk = std::min(rows, std::max(L.Nx, 1));
+    h->nchunks = (L.Nx + h->rows_per_chunk - 1) / h->rows_per_chunk;
+    if (h->nchunks > h->max_chunks) return fail(GPF_ERR_INVALID, "plan_step: chunk count exceeds the partials buffer");
+    h->plan_valid = true;
+    return GPF_OK;
+}
+
 static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, double* slab_out,
                         hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     const Layout& L = h->L;
+    GPF_TRY(plan_step(h));
+    const int mc = h->cfg.mc_order;
+    const int D = mc == 0 ? ((h->next_step % 2 == 0) ? 1 : -1) : (((mc + 1) / 2) ? 1 : -1);
+    h->next_step += 1;
+    const int np_step = h->nstrips * h->nchunks;
     StepArgs a;
     a.qa = h->q[0]; a.qb = h->q[1]; a.topo = h->topo; a.Ls = h->Ls;
     a.g1x = h->g1; a.g1y = h->g1 + 3 * L.pitch;
@@ -507,27 +550,22 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     }
     g.g1x = h->g1; g.g1y = h->g1 + 3 * L.pitch; g.st = h->st; g.L = L; g.E = h->E; g.honor_stop = honor_stop;
     FinishArgs f;
-    f.partials = h->partials; f.npartials = h->npartials + h->nghost_blocks; f.st = h->st;
+    f.partials = h->partials; f.npartials = np_step + h->nghost_blocks; f.st = h->st;
     GhostFillArgs gf;
-    gf.qa = h->q[0]; gf.qb = h->q[1]; gf.st = h->st; gf.partials = h->partials + h->npartials;
+    gf.qa = h->q[0]; gf.qb = h->q[1]; gf.st = h->st; gf.partials = h->partials + np_step;
     gf.L = L; gf.E = h->E; gf.honor_stop = honor_stop;
     f.log = h->log; f.log_base = log_base; f.log_cap = h->log_cap; f.out = slab_out; f.honor_stop = honor_stop;
 
     const int gmax = std::max(L.Nx, L.Ny);
     const dim3 ggrid((gmax + 255) / 256, 2), sgrid((h->nstrips + 3) / 4, h->nchunks);
+    const step_kernel_t kstep = step_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, D);
     EOS_DISPATCH(h->cfg.eos, {
-        if (h->Ls) {
-            hipLaunchKernelGGL((k_ghost_stage1<EOS_, true>), ggrid, dim3(256), 0, h->stream, g, h->P);
-            if (ev0) hipEventRecord(ev0, h->stream);
-            hipLaunchKernelGGL((k_step<EOS_, true>), sgrid, dim3(256), 0, h->stream, a, h->P);
-            if (ev1) hipEventRecord(ev1, h->stream);
-        } else {
-            hipLaunchKernelGGL((k_ghost_stage1<EOS_, false>), ggrid, dim3(256), 0, h->stream, g, h->P);
-            if (ev0) hipEventRecord(ev0, h->stream);
-            hipLaunchKernelGGL((k_step<EOS_, false>), sgrid, dim3(256), 0, h->stream, a, h->P);
-            if (ev1) hipEventRecord(ev1, h->stream);
-        }
-            hipLaunchKernelGGL((k_ghost_fill<EOS_>), dim3(h->nghost_blocks), dim3(256), 0, h->stream, gf, h->P);
+        if (h->Ls) hipLaunchKernelGGL((k_ghost_stage1<EOS_, true>), ggrid, dim3(256), 0, h->stream, g, h->P);
+        else hipLaunchKernelGGL((k_ghost_stage1<EOS_, false>), ggrid, dim3(256), 0, h->stream, g, h->P);
+        if (ev0) hipEventRecord(ev0, h->stream);
+        hipLaunchKernelGGL(kstep, sgrid, dim3(256), 0, h->stream, a, h->P);
+        if (ev1) hipEventRecord(ev1, h->stream);
+        hipLaunchKernelGGL((k_ghost_fill<EOS_>), dim3(h->nghost_blocks), dim3(256), 0, h->stream, gf, h->P);
     });
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, h->stream, f);
     HIP_TRY(hipGetLastError());
@@ -557,7 +595,7 @@ extern "C" int gpf_step(gpf_handle* h, int64_t n, int honor_stop, gpf_scalars_t*
                 logged += take;
             }
         }
-        h->host_step = s.step;
+        h->host_step = s.step; h->next_step = s.step;
         done += batch;
         if (ran < batch) break;     // stopped on the device (converged / max_it / invalid)
     }
@@ -590,7 +628,7 @@ extern "C" int gpf_step_timed(gpf_handle* h, int64_t n, double* kernel_ms, doubl
     for (auto& e : ev) hipEventDestroy(e);
     StepState s;
     GPF_TRY(read_state(h, s));
-    h->host_step = s.step;
+    h->host_step = s.step; h->next_step = s.step;
     return rc;
 }
 
@@ -634,7 +672,7 @@ extern "C" int gpf_step_unfused(gpf_handle* h) {
     hipLaunchKernelGGL(k_commit_unfused, dim3(1), dim3(1), 0, h->stream, h->st, pre, post);
     HIP_TRY(hipGetLastError());
     GPF_TRY(read_state(h, s));
-    h->host_step = s.step;
+    h->host_step = s.step; h->next_step = s.step;
     return GPF_OK;
 }
 
@@ -764,7 +802,7 @@ extern "C" int gpf_state(gpf_handle* h, gpf_scalars_t* out) {
     StepState s;
     GPF_TRY(read_state(h, s));
     fill_scalars(s, nullptr, 0.0, out);
-    h->host_step = s.step;
+    h->host_step = s.step; h->next_step = s.step;
     return GPF_OK;
 }
 

@@ -39,12 +39,29 @@ enum { PIEZO_NONE = 0, PIEZO_BARUS = 1, PIEZO_ROELANDS = 2, PIEZO_DUKLER = 3, PI
 // Material + kinematic constants, preprocessed on the host (see make_phys in api.hip).
 struct Phys {
     double U, V, eta, zeta;
+    double v1, v2;      // zeta + 4/3 eta, zeta - 2/3 eta for the constant-viscosity case
     double inv_dx, inv_dy;
     int eos, piezo;
     double e[12];       // EOS constants, meaning per EOS documented in make_phys
     double x[32];       // BWR: temperature-folded polynomial coefficients
     double pz[4];       // piezo-viscosity constants
 };
+
+// Reciprocal.  On gfx950 an IEEE f64 division expands to ~15 VALU instructions (div_scale, rcp,
+// four fma, div_fmas, div_fixup); v_rcp_f64 (24 good bits) + two Newton steps is 5 and was
+// measured at 0 ulp from 1.0/x over 2^20 random operands spanning 2^-60..2^60 on MI355X.  All
+// operands here (h, rho, 4Ls+h, C2-rho/rho0 ...) are far from the denormal range.
+GPF_HD double rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+#else
+    return 1.0 / x;
+#endif
+}
 
 // ---- equations of state -------------------------------------------------------------------
 
@@ -54,7 +71,7 @@ GPF_HD double eos_pressure(double rho, const Phys& P) {
         // e0=rho0 e1=P0 e2=C1 e3=C2 e4=0.99*C2*rho0 (clamp) e5=1/rho0
         double r = fmin(rho, P.e[4]);
         double s = r * P.e[5];
-        return P.e[1] + (P.e[2] * (s - 1.0)) / (P.e[3] - s);
+        return P.e[1] + (P.e[2] * (s - 1.0)) * rcp(P.e[3] - s);
     } else if (EOS == EOS_PL) {
         // e0=rho0 e1=P0 e2=alpha e3=1/(1-alpha/2)
         return P.e[1] * pow(rho / P.e[0], P.e[3]);
@@ -93,10 +110,9 @@ GPF_HD double eos_pressure(double rho, const Phys& P) {
 template <int EOS>
 GPF_HD double eos_c2(double rho, const Phys& P) {
     if (EOS == EOS_DH) {
-        // C1 rho0 (C2-1) / rho^2 / (C2 rho0/rho - 1)^2, *unclamped* rho (sound.py:109)
-        double ir = 1.0 / rho;
-        double t = P.e[3] * P.e[0] * ir - 1.0;
-        return P.e[6] * (ir * ir) / (t * t);          // e6 = C1*rho0*(C2-1)
+        // C1 rho0 (C2-1) / rho^2 / (C2 rho0/rho - 1)^2 = C1 rho0 (C2-1) / (C2 rho0 - rho)^2, *unclamped* rho (sound.py:109)
+        double it = rcp(P.e[7] - rho);                // e7 = C2*rho0
+        return P.e[6] * (it * it);                    // e6 = C1*rho0*(C2-1)
     } else if (EOS == EOS_PL) {
         // -2 P0 (rho/rho0)^(-2/(alpha-2)) / ((alpha-2) rho)
         return -2.0 * P.e[1] * pow(rho / P.e[0], -2.0 / (P.e[2] - 2.0)) / ((P.e[2] - 2.0) * rho);
@@ -169,23 +185,37 @@ struct CellFlux {
 };
 
 // Gap-averaged stress, both wall stresses, pressure: everything a stage needs from one cell.
-template <int EOS, bool WITH_SOURCE>
-GPF_HD void cell_closure(const CellIn& c, const Phys& P, CellFlux& o) {
+// Topography-only reciprocals of a cell; both stages of a step evaluate their closure on the same
+// topography, so the stencil kernel computes these once per cell and step.
+struct TopoRcp {
+    double ih, iD;          // 1/h, 1/(4 Ls + h)
+};
+
+template <bool HAS_LS>
+GPF_HD TopoRcp topo_rcp(const CellIn& c) {
+    TopoRcp t;
+    t.ih = rcp(c.h);
+    t.iD = HAS_LS ? rcp(4.0 * c.Ls + c.h) : t.ih;
+    return t;
+}
+
+// HAS_LS = false is the Ls == 0 specialisation (D = h, B = h j, ...), the common case; PIEZO = false
+// takes the constant viscosities from Phys (no per-cell exp/pow).
+template <int EOS, bool WITH_SOURCE, bool HAS_LS = true, bool PIEZO = true>
+GPF_HD void cell_closure(const CellIn& c, const TopoRcp& t, const Phys& P, CellFlux& o) {
     const double U = P.U, V = P.V;
     const double p = eos_pressure<EOS>(c.rho, P);
-    const double eta = (P.piezo == PIEZO_NONE) ? P.eta : piezo_eta(P.eta, (EOS == EOS_BAYADA) ? c.rho : p, P);
-    const double v1 = P.zeta + (4.0 / 3.0) * eta;
-    const double v2 = P.zeta - (2.0 / 3.0) * eta;
+    const double eta = (!PIEZO || P.piezo == PIEZO_NONE) ? P.eta : piezo_eta(P.eta, (EOS == EOS_BAYADA) ? c.rho : p, P);
+    const double v1 = PIEZO ? P.zeta + (4.0 / 3.0) * eta : P.v1;
+    const double v2 = PIEZO ? P.zeta - (2.0 / 3.0) * eta : P.v2;
 
-    const double D = 4.0 * c.Ls + c.h;
-    const double ih = 1.0 / c.h, ir = 1.0 / c.rho, iD = 1.0 / D;
+    const double ih = t.ih, iD = t.iD, ir = rcp(c.rho);
     const double irD = ir * iD;         // 1/(rho D)
     const double ihrD = ih * irD;       // 1/(h rho D)
 
     const double Urho = U * c.rho, Vrho = V * c.rho;
-    const double hm = c.h - 2.0 * c.Ls;
-    const double Bx = 2.0 * c.Ls * Urho + hm * c.jx;
-    const double By = 2.0 * c.Ls * Vrho + hm * c.jy;
+    const double Bx = HAS_LS ? 2.0 * c.Ls * Urho + (c.h - 2.0 * c.Ls) * c.jx : c.h * c.jx;
+    const double By = HAS_LS ? 2.0 * c.Ls * Vrho + (c.h - 2.0 * c.Ls) * c.jy : c.h * c.jy;
     const double hxBx = c.hx * Bx, hyBy = c.hy * By;
     const double txx = (v1 * hxBx + v2 * hyBy) * ihrD;
     const double tyy = (v2 * hxBx + v1 * hyBy) * ihrD;
@@ -197,7 +227,7 @@ GPF_HD void cell_closure(const CellIn& c, const Phys& P, CellFlux& o) {
     o.fy2 = p + tyy;
 
     if (WITH_SOURCE) {
-        const double w = 3.0 * c.Ls + c.h;
+        const double w = HAS_LS ? 3.0 * c.Ls + c.h : c.h;
         const double gx = 3.0 * c.jx - Urho, gy = 3.0 * c.jy - Vrho;
         const double Ax = w * gx, Ay = w * gy;
         const double t2 = 2.0 * irD * iD;                         // 2/(rho D^2)
@@ -209,7 +239,8 @@ GPF_HD void cell_closure(const CellIn& c, const Phys& P, CellFlux& o) {
         const double txz_t = -e2 * gx;                            // 2 eta (U rho - 3 jx)/(rho D)
         const double tyz_t = -e2 * gy;
         // bottom: 2 eta [(6Ls+3h) j - (6Ls+2h) W rho] / (h rho D)
-        const double a3 = 6.0 * c.Ls + 3.0 * c.h, a2 = 6.0 * c.Ls + 2.0 * c.h;
+        const double a3 = HAS_LS ? 6.0 * c.Ls + 3.0 * c.h : 3.0 * c.h;
+        const double a2 = HAS_LS ? 6.0 * c.Ls + 2.0 * c.h : 2.0 * c.h;
         const double e2h = e2 * ih;
         const double txz_b = e2h * (a3 * c.jx - a2 * Urho);
         const double tyz_b = e2h * (a3 * c.jy - a2 * Vrho);
@@ -218,6 +249,11 @@ GPF_HD void cell_closure(const CellIn& c, const Phys& P, CellFlux& o) {
         o.s1 = ((txx - txx_t) * c.hx + (txy - txy_t) * c.hy + txz_t - txz_b) * ih;
         o.s2 = ((txy - txy_t) * c.hx + (tyy - tyy_t) * c.hy + tyz_t - tyz_b) * ih;
     }
+}
+
+template <int EOS, bool WITH_SOURCE, bool HAS_LS = true, bool PIEZO = true>
+GPF_HD void cell_closure(const CellIn& c, const Phys& P, CellFlux& o) {
+    cell_closure<EOS, WITH_SOURCE, HAS_LS, PIEZO>(c, topo_rcp<HAS_LS>(c), P, o);
 }
 
 // The full set of derived fields the reference keeps per cell (for gpf_update_closures).

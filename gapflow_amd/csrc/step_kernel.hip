@@ -70,7 +70,7 @@ __device__ __forceinline__ int predictor_direction(const StepState* st) {
     return ((st->mc_order + 1) / 2) ? 1 : -1;      // [[-1,1],[1,-1]][(switch+1)//2]
 }
 
-template <int EOS, bool HAS_LS, int D>
+template <int EOS, bool HAS_LS, bool PIEZO, int D>
 __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, const double* __restrict__ qin,
                                            double* __restrict__ qout) {
     const Layout L = a.L;
@@ -99,10 +99,14 @@ __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, con
     const double* __restrict__ hp = a.topo;
     const double* __restrict__ hxp = a.topo + L.plane;
     const double* __restrict__ hyp = a.topo + 2 * L.plane;
+    double* __restrict__ qo0 = qout;
+    double* __restrict__ qo1 = qout + L.plane;
+    double* __restrict__ qo2 = qout + 2 * L.plane;
 
+    // per-lane element offsets fit 32 bits (a plane is < 2^28 doubles); the plane bases stay in SGPRs
     auto load = [&](int n, CellIn& c) {
         const int ix = D > 0 ? n : L.Nx + 1 - n;
-        const long long o = L.at(ix, iy);
+        const int o = ix * L.pitch + L.off + iy;
         c.rho = q0p[o]; c.jx = q1p[o]; c.jy = q2p[o];
         c.h = hp[o]; c.hx = hxp[o]; c.hy = hyp[o];
         c.Ls = HAS_LS ? a.Ls[o] : 0.0;
@@ -113,8 +117,7 @@ __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, con
 
     // carried from the previous row
     double fx1p0 = 0, fx1p1 = 0, fx1p2 = 0;     // stage-1 x-flux of row n-1
-    double part0 = 0, part1 = 0, part2 = 0;     // row n-1: q1 - dt*(-cx*Fx2 + cy*dFy2 - S2)
-    double a0 = 0, a1 = 0, a2 = 0;              // row n-1: q at time level 0
+    double part0 = 0, part1 = 0, part2 = 0;     // row n-1: q(t0) + q1 - dt*(-cx*Fx2 + cy*dFy2 - S2)
     // reductions over this wave's output cells
     double r_ekin = 0.0, r_v2 = 0.0, r_c2 = 0.0;
     int r_flags = 0;
@@ -125,6 +128,8 @@ __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, con
         const bool last = (n == n_last + 1);
         const int ix = D > 0 ? n : L.Nx + 1 - n;
 
+        const TopoRcp tr = topo_rcp<HAS_LS>(cur);           // shared by both stages of this cell
+
         // ---- stage 1 at (n, m) ----
         double q10, q11, q12;
         if (last && dw_row_is_ghost) {
@@ -133,7 +138,7 @@ __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, con
             q12 = a.g1x[2 * L.pitch + L.off + iy];
         } else {
             CellFlux f;
-            cell_closure<EOS, true>(cur, P, f);
+            cell_closure<EOS, true, HAS_LS, PIEZO>(cur, tr, P, f);
             const double fy0 = cur.jy, fy1 = f.fx2, fy2 = f.fy2;
             const double u0 = __shfl_up(fy0, 1), u1 = __shfl_up(fy1, 1), u2 = __shfl_up(fy2, 1);
             q10 = cur.rho - dt * (cx * (cur.jx - fx1p0) + cy * (fy0 - u0) - f.s0);
@@ -152,22 +157,22 @@ __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, con
             CellIn c1 = cur;
             c1.rho = q10; c1.jx = q11; c1.jy = q12;
             CellFlux g;
-            cell_closure<EOS, true>(c1, P, g);
+            cell_closure<EOS, true, HAS_LS, PIEZO>(c1, tr, P, g);
             const double gy0 = q12, gy1 = g.fx2, gy2 = g.fy2;
             const double d0 = __shfl_down(gy0, 1), d1 = __shfl_down(gy1, 1), d2 = __shfl_down(gy2, 1);
 
             // ---- finish row n-1: corrector + time average (problem.py:558, 563) ----
             if (n > n_first) {
-                const double o0 = 0.5 * ((part0 - dt * cx * q11) + a0);
-                const double o1 = 0.5 * ((part1 - dt * cx * g.fx1) + a1);
-                const double o2 = 0.5 * ((part2 - dt * cx * g.fx2) + a2);
+                const double o0 = 0.5 * (part0 - dt * cx * q11);
+                const double o1 = 0.5 * (part1 - dt * cx * g.fx1);
+                const double o2 = 0.5 * (part2 - dt * cx * g.fx2);
                 if (col_out) {
                     const int ixo = D > 0 ? n - 1 : L.Nx + 2 - n;
-                    const long long o = L.at(ixo, iy);
-                    qout[o] = o0;
-                    qout[o + L.plane] = o1;
-                    qout[o + 2 * L.plane] = o2;
-                    const double v2 = (o1 * o1 + o2 * o2) / o0;
+                    const int o = ixo * L.pitch + L.off + iy;
+                    qo0[o] = o0;
+                    qo1[o] = o1;
+                    qo2[o] = o2;
+                    const double v2 = (o1 * o1 + o2 * o2) * rcp(o0);
                     // a row next to a periodic slab seam also stands in for the far slab's ghost row
                     const double w = 1.0 + ((ixo == 1 && a.E.halo[0] == 2) ? 1.0 : 0.0) +
                                      ((ixo == L.Nx && a.E.halo[1] == 2) ? 1.0 : 0.0);
@@ -181,10 +186,9 @@ __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, con
                 }
             }
             // ---- open row n (an output row unless this is the downwind extra row) ----
-            part0 = q10 - dt * (-cx * q11 + cy * (d0 - gy0) - g.s0);
-            part1 = q11 - dt * (-cx * g.fx1 + cy * (d1 - gy1) - g.s1);
-            part2 = q12 - dt * (-cx * g.fx2 + cy * (d2 - gy2) - g.s2);
-            a0 = cur.rho; a1 = cur.jx; a2 = cur.jy;
+            part0 = (cur.rho + q10) - dt * (-cx * q11 + cy * (d0 - gy0) - g.s0);
+            part1 = (cur.jx + q11) - dt * (-cx * g.fx1 + cy * (d1 - gy1) - g.s1);
+            part2 = (cur.jy + q12) - dt * (-cx * g.fx2 + cy * (d2 - gy2) - g.s2);
         }
         cur = nxt;
     }
@@ -203,16 +207,16 @@ __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, con
     }
 }
 
-template <int EOS, bool HAS_LS>
+// D = direction of the predictor, chosen by the host from the step index (problem.py:521-522);
+// the device-side step counter is checked against it so a disagreement can never go unnoticed.
+template <int EOS, bool HAS_LS, bool PIEZO, int D>
 __global__ __launch_bounds__(256) void k_step(const StepArgs a, const Phys P) {
     if (halted(a.st, a.honor_stop)) return;
+    if (predictor_direction(a.st) != D) __builtin_trap();
     const int par = a.st->parity;
     const double* qin = par ? a.qb : a.qa;
     double* qout = const_cast<double*>(par ? a.qa : a.qb);
-    if (predictor_direction(a.st) > 0)
-        step_strip<EOS, HAS_LS, 1>(a, P, qin, qout);
-    else
-        step_strip<EOS, HAS_LS, -1>(a, P, qin, qout);
+    step_strip<EOS, HAS_LS, PIEZO, D>(a, P, qin, qout);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -256,9 +260,9 @@ __device__ __forceinline__ void stage1_at(const double* __restrict__ q, const Gh
     cell(ixq_up, iy, tup, lup, cxu);
     cell(ix, iy - D, tsrc, lsrc, cyu);
     CellFlux f, fxu, fyu;
-    cell_closure<EOS, true>(c, P, f);
-    cell_closure<EOS, false>(cxu, P, fxu);
-    cell_closure<EOS, false>(cyu, P, fyu);
+    cell_closure<EOS, true, HAS_LS, true>(c, P, f);
+    cell_closure<EOS, false, HAS_LS, true>(cxu, P, fxu);
+    cell_closure<EOS, false, HAS_LS, true>(cyu, P, fyu);
     const double cx = (double)D * P.inv_dx, cy = (double)D * P.inv_dy;
     out[0] = c.rho - dt * (cx * (c.jx - cxu.jx) + cy * (c.jy - cyu.jy) - f.s0);
     out[1] = c.jx - dt * (cx * (f.fx1 - fxu.fx1) + cy * (f.fx2 - fyu.fx2) - f.s1);
