@@ -76,10 +76,33 @@ class GapflowHipError(RuntimeError):
     pass
 
 
+def _pin_hip_runtime():
+    """Make sure ONE HIP runtime serves this process.
+
+    PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Whichever copy is
+    mapped first wins, and a process that maps /opt/rocm's first cannot initialise torch.cuda afterwards
+    ("No HIP GPUs are available").  The slab path needs torch.distributed next to this library, so when
+    torch is installed its bundled runtime is mapped first -- without importing torch."""
+    import sys
+    if 'torch' in sys.modules or os.environ.get('GPF_SYSTEM_HIP') == '1':
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Load libgapflow_hip.so once; raises if it has not been built (python -m gapflow_amd.build)."""
     global _lib
     if _lib is None:
+        _pin_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise GapflowHipError(
                 f"{LIB_PATH} not found: build it with `python -m gapflow_amd.build` (needs hipcc). "

@@ -1,0 +1,250 @@
+"""x-slab decomposition of one problem over the GPUs of a node: one process per GPU.
+
+The reference is single-process (README.md:60-61); this module is new.  The grid is cut along x
+(the slow axis of the device planes, so halo rows are contiguous).  A fused step needs its
+neighbours' field only one row deep (the composed MacCormack stencil has radius 1, see
+csrc/step_kernel.hip), so per time step each rank exchanges ONE row with each neighbour and
+all-gathers one 64-byte record (sum Ekin, max v^2, max c^2, validity) -- both after the stencil
+kernel, before the dt/residual commit:
+
+    gpf_step_local   (prepass + fused stencil + local ghost rules + pack send rows + local record)
+    all_gather(record)  |  isend/irecv(halo rows)          <- torch.distributed (RCCL over xGMI)
+    gpf_step_commit  (scatter received rows, reduce records in rank order, advance dt/residual)
+
+Everything is enqueued on one stream; there is no host synchronisation inside `advance`.
+Reductions are combined in rank order on every rank, so all ranks hold bit-identical dt.
+
+Kinds of a slab's outer rows (gpf_config.halo_lo/hi): 0 physical ghost row (local rule),
+1 copy of the neighbour's interior row, 2 the domain's periodic ghost row (filled by the ring).
+
+`SlabDriver` is backend-neutral (any engine with step_local / halo_tensors / commit); the product
+engine is `HipSlabEngine`.  tests/test_slab_gloo.py drives the same driver with a CPU engine over
+gloo to check partitioning, message pairing and the rank-ordered reduction.
+"""
+import ctypes as C
+import io as _io
+from copy import deepcopy
+
+import numpy as np
+
+from . import _lib
+from .io import read_yaml_input
+from .topography import Topography
+
+HALO_PHYSICAL, HALO_NEIGHBOUR, HALO_SEAM = 0, 1, 2
+
+
+def partition(Nx, world):
+    """Global interior rows [lo, hi] (1-based, inclusive) of every rank; remainders go to the first ranks."""
+    base, rem = divmod(Nx, world)
+    if base < 1:
+        raise ValueError(f"cannot cut Nx={Nx} rows into {world} slabs")
+    out, lo = [], 1
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((lo, lo + n - 1))
+        lo += n
+    return out
+
+
+class SlabLayout:
+    """Everything a rank needs to know about its slab."""
+
+    def __init__(self, grid, rank, world):
+        self.rank, self.world = rank, world
+        self.Nx_global = grid['Nx']
+        self.lo, self.hi = partition(grid['Nx'], world)[rank]
+        self.nx = self.hi - self.lo + 1
+        periodic = all(grid['bc_xE_P']) and all(grid['bc_xW_P'])
+        self.periodic = periodic
+        first, last = rank == 0, rank == world - 1
+        if world == 1:
+            self.kind_lo = self.kind_hi = HALO_PHYSICAL
+            self.lower = self.upper = None
+        else:
+            self.kind_lo = (HALO_SEAM if periodic else HALO_PHYSICAL) if first else HALO_NEIGHBOUR
+            self.kind_hi = (HALO_SEAM if periodic else HALO_PHYSICAL) if last else HALO_NEIGHBOUR
+            self.lower = (world - 1 if periodic else None) if first else rank - 1
+            self.upper = (0 if periodic else None) if last else rank + 1
+
+    def rows(self):
+        """Slice of the global (Nx+2)-row arrays held by this rank, including its two outer rows."""
+        return slice(self.lo - 1, self.hi + 2)
+
+    def local_grid(self, grid):
+        g = deepcopy(grid)
+        g['Nx'] = self.nx
+        g['Lx'] = grid['dx'] * self.nx
+        return g
+
+
+def exchange_and_gather(layout, record, gathered, send_lo, send_hi, recv_lo, recv_hi, dist):
+    """One all-gather of the 8-double records and one paired halo exchange.
+
+    Message pairing relies on issue order (RCCL has no tags): every rank posts
+    send_hi -> upper, recv_lo <- lower, send_lo -> lower, recv_hi <- upper, so that with two ranks on a
+    periodic ring (lower == upper) the first receive still meets the peer's first send."""
+    dist.all_gather_into_tensor(gathered, record)
+    ops = []
+    if layout.upper is not None:
+        ops.append(dist.P2POp(dist.isend, send_hi, layout.upper))
+    if layout.lower is not None:
+        ops.append(dist.P2POp(dist.irecv, recv_lo, layout.lower))
+        ops.append(dist.P2POp(dist.isend, send_lo, layout.lower))
+    if layout.upper is not None:
+        ops.append(dist.P2POp(dist.irecv, recv_hi, layout.upper))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
+class SlabDriver:
+    """Runs the split step of an engine: step_local -> (gather | exchange) -> commit."""
+
+    def __init__(self, engine, layout, dist, torch):
+        self.engine, self.layout, self.dist = engine, layout, dist
+        self.send_lo, self.send_hi, self.recv_lo, self.recv_hi = engine.halo_tensors()
+        self.gathered = torch.zeros(8 * layout.world, dtype=torch.float64, device=self.send_lo.device)
+
+    def advance(self, n, honor_stop=False):
+        for _ in range(n):
+            record = self.engine.step_local(honor_stop)
+            exchange_and_gather(self.layout, record, self.gathered, self.send_lo, self.send_hi,
+                                self.recv_lo, self.recv_hi, self.dist)
+            self.engine.commit(self.gathered, honor_stop)
+
+
+class _DeviceArray:
+    """Exposes library-owned device memory to torch through the CUDA array interface (no copy)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {'shape': (n,), 'typestr': '<f8', 'data': (int(ptr), False), 'version': 2}
+
+
+class HipSlabEngine:
+    """The product engine: one libgapflow_hip handle per rank."""
+
+    def __init__(self, lib, handle, torch, world):
+        self.lib, self.h, self.torch, self.world = lib, handle, torch, world
+        p = [C.c_void_p() for _ in range(4)]
+        n = C.c_size_t(0)
+        _lib.check(lib.gpf_halo_buffers(handle, *[C.byref(x) for x in p], C.byref(n)))
+        self._bufs = [torch.as_tensor(_DeviceArray(x.value, n.value), device='cuda') for x in p]
+        self._rec_ptr = None
+        self._rec = None
+
+    def halo_tensors(self):
+        return self._bufs
+
+    def step_local(self, honor_stop):
+        rec = C.c_void_p()
+        _lib.check(self.lib.gpf_step_local(self.h, int(honor_stop), C.byref(rec)))
+        if self._rec_ptr != rec.value:
+            self._rec_ptr = rec.value
+            self._rec = self.torch.as_tensor(_DeviceArray(rec.value, 8), device='cuda')
+        return self._rec
+
+    def commit(self, gathered, honor_stop):
+        _lib.check(self.lib.gpf_step_commit(self.h, int(honor_stop), C.c_void_p(gathered.data_ptr()), self.world))
+
+
+class SlabProblem:
+    """A Problem cut into x-slabs; construct it on every rank of an initialised process group."""
+
+    def __init__(self, input_dict, device=0, dist=None):
+        import torch
+        if dist is None:
+            import torch.distributed as dist
+        if input_dict.get('gp') is not None or input_dict.get('db') is not None:
+            raise NotImplementedError("GP closures are not available in slab mode yet")
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.input = input_dict
+        grid, prop, geo = input_dict['grid'], input_dict['properties'], input_dict['geometry']
+        self.layout = L = SlabLayout(grid, self.rank, self.world)
+        self.lib = _lib.require_device()
+
+        # the serial problem's configuration, narrowed to this slab
+        from .problem import Problem
+        shell = Problem.__new__(Problem)
+        shell.options, shell.numerics, shell.prop, shell.geo = input_dict['options'], input_dict['numerics'], prop, geo
+        shell.grid = L.local_grid(grid)
+        cfg = shell._make_config(device)
+        cfg.halo_lo, cfg.halo_hi = L.kind_lo, L.kind_hi
+        self.grid_local = shell.grid
+        self._h = C.c_void_p()
+        _lib.check(self.lib.gpf_create(C.byref(cfg), C.byref(self._h)))
+        _lib.check(self.lib.gpf_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+        # global topography on the host, sliced (profiles such as `asperity` need global cell means)
+        topo = Topography(grid, geo, prop).full
+        rows = L.rows()
+        shape = (L.nx + 2, grid['Ny'] + 2)
+        self._shape = shape
+        self._upload(_lib.FIELD_TOPO, topo[:3, rows])
+        q = np.empty((3,) + shape)
+        q[0], q[1], q[2] = prop['rho0'], prop['rho0'] * geo['U'] / 2.0, prop['rho0'] * geo['V'] / 2.0
+        self._upload(_lib.FIELD_Q, q)
+        nxg = grid['Nx']
+        for side, kind, (r_src, r_up) in ((0, L.kind_lo, (nxg, nxg + 1)), (1, L.kind_hi, (1, 0))):
+            if kind == HALO_SEAM:
+                seam = np.zeros((2, 4, grid['Ny'] + 2))
+                seam[0, :3], seam[1, :3] = topo[:3, r_src], topo[:3, r_up]
+                seam = _lib.f64c(seam)
+                _lib.check(self.lib.gpf_set_seam_topo(self._h, side, _lib.as_dp(seam), seam.size))
+        self.engine = HipSlabEngine(self.lib, self._h, torch, self.world)
+        self.driver = SlabDriver(self.engine, L, dist, torch)
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h is not None and h.value:
+            self.lib.gpf_destroy(h)
+            h.value = None
+
+    @classmethod
+    def from_string(cls, text, device=0, dist=None):
+        with _io.StringIO(text) as f:
+            return cls(read_yaml_input(f), device=device, dist=dist)
+
+    @classmethod
+    def from_yaml(cls, fname, device=0):
+        with open(fname) as f:
+            return cls(read_yaml_input(f), device=device)
+
+    def _upload(self, field, arr):
+        a = _lib.f64c(arr)
+        _lib.check(self.lib.gpf_upload(self._h, field, _lib.as_dp(a), a.size))
+
+    def global_scalars(self):
+        """Ekin, v_max, v_sound, mass over the whole domain (sum / max over the slabs)."""
+        sc = _lib.GpfScalars()
+        _lib.check(self.lib.gpf_scalars(self._h, C.byref(sc)))
+        t = self.torch
+        s = t.tensor([sc.ekin, sc.mass], dtype=t.float64, device='cuda')
+        m = t.tensor([sc.v_max, sc.v_sound], dtype=t.float64, device='cuda')
+        self.dist.all_reduce(s, op=self.dist.ReduceOp.SUM)
+        self.dist.all_reduce(m, op=self.dist.ReduceOp.MAX)
+        return {'ekin': float(s[0]), 'mass': float(s[1]), 'v_max': float(m[0]), 'v_sound': float(m[1])}
+
+    def pre_run(self):
+        """Problem._pre_run (problem.py:412-443) with domain-wide scalars."""
+        _lib.check(self.lib.gpf_pre_run(self._h))
+        g = self.global_scalars()
+        num, grid = self.input['numerics'], self.input['grid']
+        dt_crit = min(grid['dx'], grid['dy']) / (g['v_max'] + g['v_sound'])
+        dt = num['CFL'] * dt_crit if num['adaptive'] else num['dt']
+        _lib.check(self.lib.gpf_set_dt(self._h, float(dt)))
+        _lib.check(self.lib.gpf_set_ekin_old(self._h, float(g['ekin'])))
+
+    def advance(self, n, honor_stop=False):
+        self.driver.advance(n, honor_stop)
+
+    def state(self):
+        sc = _lib.GpfScalars()
+        _lib.check(self.lib.gpf_state(self._h, C.byref(sc)))
+        return sc
+
+    def local_q(self):
+        out = np.empty((3,) + self._shape)
+        _lib.check(self.lib.gpf_download(self._h, _lib.FIELD_Q, _lib.as_dp(out), out.size))
+        return out
