@@ -20,8 +20,9 @@ PIEZO_KEYS = {'Barus': ['aB'], 'Roelands': ['mu_inf', 'p_ref', 'z'], 'Dukler': [
               'McAdams': ['eta_v', 'rho_l', 'rho_v']}
 BC_P, BC_D, BC_N = 0, 1, 2
 FIELD_Q, FIELD_TOPO, FIELD_EXTRA, FIELD_PRESSURE, FIELD_TAU_AVG, FIELD_WALL_LOWER, FIELD_WALL_UPPER = range(7)
+FIELD_PRESSURE_VAR, FIELD_WALL_XZ_VAR, FIELD_WALL_YZ_VAR = 7, 8, 9
 FIELD_NCOMP = {FIELD_Q: 3, FIELD_TOPO: 3, FIELD_EXTRA: 1, FIELD_PRESSURE: 1, FIELD_TAU_AVG: 3,
-               FIELD_WALL_LOWER: 6, FIELD_WALL_UPPER: 6}
+               FIELD_WALL_LOWER: 6, FIELD_WALL_UPPER: 6, 7: 1, 8: 1, 9: 1}
 
 
 class GpfConfig(C.Structure):
@@ -67,6 +68,15 @@ SIGNATURES = {
     'gpf_set_seam_topo': (C.c_int, [C.c_void_p, C.c_int, _DP, C.c_size_t]),
     'gpf_predictor_corrector': (C.c_int, [C.c_int, C.c_int, _DP, _DP, _DP, C.c_int, _DP, _DP]),
     'gpf_source': (C.c_int, [C.c_int, C.c_int, _DP, _DP, _DP, _DP, _DP, _DP]),
+    'gpf_open_step': (C.c_int, [C.c_void_p]),
+    'gpf_stage_closures': (C.c_int, [C.c_void_p]),
+    'gpf_stage_advance': (C.c_int, [C.c_void_p, C.c_int]),
+    'gpf_close_step': (C.c_int, [C.c_void_p, C.POINTER(GpfScalars)]),
+    'gpf_gp_fit': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _DP, _DP, C.c_double, _DP, C.c_double, _DP, _DP, _DP]),
+    'gpf_gp_set_model': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), _DP, _DP, _DP,
+                                   C.c_double, _DP, C.c_double, C.c_double]),
+    'gpf_gp_clear_model': (C.c_int, [C.c_void_p, C.c_int]),
+    'gpf_gp_variance': (C.c_int, [C.c_void_p, C.c_int, C.c_int, _DP]),
 }
 
 _lib = None

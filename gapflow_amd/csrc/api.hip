@@ -11,10 +11,13 @@
 #include "../../include/gapflow_hip.h"
 #include "step_kernel.hip"
 #include "aux_kernels.hip"
+#include "gp_kernels.hip"
 
 using namespace gpf;
 
 static thread_local std::string g_err;
+static const bool g_debug = std::getenv("GPF_DEBUG") != nullptr;
+#define DBG(...) do { if (g_debug) { std::fprintf(stderr, "[gpf] " __VA_ARGS__); std::fprintf(stderr, "\n"); std::fflush(stderr); } } while (0)
 
 static int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -62,6 +65,21 @@ struct gpf_handle {
     // unfused pipeline scratch (lazy)
     double* fields = nullptr;               // p(1) tau(3) lower(6) upper(6)
     double* work = nullptr;                 // fx(3) fy(3) src(3)
+    // GP surrogate models: 0 pressure, 1 wall shear xz, 2 wall shear yz
+    struct GpHost {
+        bool set = false;
+        GpModelDev dev;
+        double *Z = nullptr, *alpha = nullptr, *L = nullptr;
+        double xscale0 = 1.0;
+    } gp[3];
+    double* gpvar = nullptr;                // 3 variance planes
+    double* gpscratch = nullptr;            // block maxima + 4 result slots
+    int gpscratch_n = 0;
+    double* gptile = nullptr;               // Ks tile for the variance solve
+    size_t gptile_doubles = 0;
+    void* blas = nullptr;
+    bool step_open = false;                 // an unfused step is in progress on buffer parity^1
+    int open_parity = 0;
     bool has_q = false, has_topo = false, pre_run_done = false;
     long long host_step = 0;                // step count at the last sync
     long long next_step = 0;                // index of the next step to be enqueued (== device step unless halted)
@@ -249,7 +267,10 @@ extern "C" int gpf_destroy(gpf_handle* h) {
     if (!h) return GPF_OK;
     hipSetDevice(h->cfg.device);
     void* ptrs[] = {h->q[0], h->q[1], h->topo, h->Ls, h->g1, h->seam, h->halo, h->st, h->partials, h->spart,
-                    h->log, h->stage, h->fields, h->work};
+                    h->log, h->stage, h->fields, h->work, h->gpvar, h->gpscratch, h->gptile,
+                    h->gp[0].Z, h->gp[0].alpha, h->gp[0].L, h->gp[1].Z, h->gp[1].alpha, h->gp[1].L,
+                    h->gp[2].Z, h->gp[2].alpha, h->gp[2].L};
+    if (h->blas && roclibs().ok) roclibs().destroy(h->blas);
     for (void* p : ptrs)
         if (p) hipFree(p);
     delete h;
@@ -272,6 +293,7 @@ static int field_ncomp(int field) {
     case GPF_FIELD_TAU_AVG: return 3;
     case GPF_FIELD_WALL_LOWER: return 6;
     case GPF_FIELD_WALL_UPPER: return 6;
+    case GPF_FIELD_PRESSURE_VAR: case GPF_FIELD_WALL_XZ_VAR: case GPF_FIELD_WALL_YZ_VAR: return 1;
     }
     return 0;
 }
@@ -345,6 +367,10 @@ extern "C" int gpf_download(gpf_handle* h, int field, double* host, size_t count
     case GPF_FIELD_EXTRA:
         if (!h->Ls) { std::memset(host, 0, count * sizeof(double)); return GPF_OK; }
         src = h->Ls; break;
+    case GPF_FIELD_PRESSURE_VAR: case GPF_FIELD_WALL_XZ_VAR: case GPF_FIELD_WALL_YZ_VAR:
+        if (!h->gpvar) return fail(GPF_ERR_STATE, "gpf_download: no GP variance has been computed");
+        src = h->gpvar + (size_t)(field - GPF_FIELD_PRESSURE_VAR) * L.plane;
+        break;
     default:
         if (!h->fields) return fail(GPF_ERR_STATE, "gpf_download: derived fields requested before gpf_update_closures");
         src = h->fields + (field == GPF_FIELD_PRESSURE ? 0 : field == GPF_FIELD_TAU_AVG ? 1 : field == GPF_FIELD_WALL_LOWER ? 4 : 10) * L.plane;
@@ -363,6 +389,8 @@ static FieldPtrs field_ptrs(gpf_handle* h) {
     return F;
 }
 
+static int gp_launch_mean(gpf_handle* h, int which, const double* q, bool with_grad, double* c2_out);
+
 static int launch_fields(gpf_handle* h, const double* q) {
     GPF_TRY(ensure_fields(h));
     const Layout& L = h->L;
@@ -373,6 +401,8 @@ static int launch_fields(gpf_handle* h, const double* q) {
         else hipLaunchKernelGGL((k_fields<EOS_, false>), dim3(blocks_for(n)), dim3(256), 0, h->stream, q, h->topo, (const double*)nullptr, F, L, h->P);
     });
     HIP_TRY(hipGetLastError());
+    for (int w = 0; w < 3; ++w)
+        if (h->gp[w].set) GPF_TRY(gp_launch_mean(h, w, q, false, nullptr));
     return GPF_OK;
 }
 
@@ -401,6 +431,8 @@ static int launch_scalars(gpf_handle* h, const double* q, ScalarPartial* total) 
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_scalars_final, dim3(1), dim3(256), 0, h->stream, h->spart, nb, total);
     HIP_TRY(hipGetLastError());
+    // with a pressure surrogate the sound speed is the steepest slope of the GP mean (stress.py:533-537)
+    if (h->gp[0].set) GPF_TRY(gp_launch_mean(h, 0, q, true, &total->c2));
     return GPF_OK;
 }
 
@@ -635,45 +667,23 @@ extern "C" int gpf_step_timed(gpf_handle* h, int64_t n, double* kernel_ms, doubl
 // ---------------------------------------------------------------------------------------------
 // the unfused, reference-ordered step (problem.py:509-586 line by line)
 // ---------------------------------------------------------------------------------------------
+extern "C" int gpf_open_step(gpf_handle* h);
+extern "C" int gpf_stage_closures(gpf_handle* h);
+extern "C" int gpf_stage_advance(gpf_handle* h, int stage);
+extern "C" int gpf_close_step(gpf_handle* h, gpf_scalars_t* out);
+
 extern "C" int gpf_step_unfused(gpf_handle* h) {
     if (!h) return fail(GPF_ERR_INVALID, "null handle");
     if (!h->pre_run_done) return fail(GPF_ERR_STATE, "gpf_step_unfused: call gpf_pre_run first");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    const Layout& L = h->L;
-    GPF_TRY(ensure_fields(h));
-    if (!h->work) HIP_TRY(hipMalloc(&h->work, (size_t)9 * L.plane * sizeof(double)));
     StepState s;
     GPF_TRY(read_state(h, s));
     if (s.invalid) return GPF_OK;
-    const double* q0 = h->q[s.parity];
-    double* q = h->q[s.parity ^ 1];
-    const long long n = (long long)(L.Nx + 2) * (L.Ny + 2);
-    const int nb = blocks_for(n);
-    double *fx = h->work, *fy = h->work + 3 * L.plane, *src = h->work + 6 * L.plane;
-    FieldPtrs F = field_ptrs(h);
-    hipLaunchKernelGGL(k_copy3, dim3(blocks_for(3 * L.plane)), dim3(256), 0, h->stream, q0, q, 3 * L.plane);
-    const int sw = s.mc_order == 0 ? ((s.step % 2 == 0) ? 1 : -1) : s.mc_order;
-    const int dirs[2] = {((sw + 1) / 2) ? 1 : -1, ((sw + 1) / 2) ? -1 : 1};
+    GPF_TRY(gpf_open_step(h));
     for (int i = 0; i < 2; ++i) {
-        GPF_TRY(launch_fields(h, q));
-        hipLaunchKernelGGL(k_fluxdiff, dim3(nb), dim3(256), 0, h->stream, q, F.p, F.tau, dirs[i], fx, fy, L);
-        hipLaunchKernelGGL(k_source, dim3(nb), dim3(256), 0, h->stream, q, h->topo, F.tau, F.lower, F.upper, src, L);
-        hipLaunchKernelGGL(k_axpy, dim3(nb), dim3(256), 0, h->stream, q, fx, fy, src, h->st, h->cfg.dx, h->cfg.dy, L);
-        hipLaunchKernelGGL(k_bc_x, dim3((L.Ny + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
-        hipLaunchKernelGGL(k_bc_y, dim3((L.Nx + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
+        GPF_TRY(gpf_stage_closures(h));
+        GPF_TRY(gpf_stage_advance(h, i));
     }
-    hipLaunchKernelGGL(k_average, dim3(nb), dim3(256), 0, h->stream, q, q0, L);
-    ScalarPartial* pre = h->spart + h->nspart;
-    ScalarPartial* post = h->spart + h->nspart + 1;
-    GPF_TRY(launch_scalars(h, q, pre));                 // validity of the averaged field (problem.py:565)
-    hipLaunchKernelGGL(k_bc_x, dim3((L.Ny + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
-    hipLaunchKernelGGL(k_bc_y, dim3((L.Nx + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
-    GPF_TRY(launch_scalars(h, q, post));                // scalars after the ghost update (problem.py:576-578)
-    hipLaunchKernelGGL(k_commit_unfused, dim3(1), dim3(1), 0, h->stream, h->st, pre, post);
-    HIP_TRY(hipGetLastError());
-    GPF_TRY(read_state(h, s));
-    h->host_step = s.step; h->next_step = s.step;
-    return GPF_OK;
+    return gpf_close_step(h, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -820,5 +830,346 @@ extern "C" int gpf_set_seam_topo(gpf_handle* h, int side, const double* host, si
         for (int iy = 0; iy < L.Ny + 2; ++iy) tmp[(size_t)r * L.pitch + L.off + iy] = host[(size_t)r * (L.Ny + 2) + iy];
     HIP_TRY(hipMemcpy(h->seam + (size_t)side * 8 * L.pitch, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
     h->has_seam[side] = true;
+    return GPF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GP surrogate closure (gp_kernels.hip)
+// ---------------------------------------------------------------------------------------------
+static int gp_blas(gpf_handle* h, void** out) {
+    RocLibs& R = roclibs();
+    if (!R.ok) return fail(GPF_ERR_SOLVER, R.err);
+    if (!h->blas) {
+        if (R.create(&h->blas) != 0) return fail(GPF_ERR_SOLVER, "rocblas_create_handle failed");
+    }
+    if (R.set_stream(h->blas, h->stream) != 0) return fail(GPF_ERR_SOLVER, "rocblas_set_stream failed");
+    *out = h->blas;
+    return GPF_OK;
+}
+
+// Builds K from kernel-coordinate inputs Z (device, [n][d]), factorises it in place (column-major lower),
+// solves for alpha (device, column-major [n][m], holds Y on entry).  *info_host != 0: not positive definite.
+static int gp_factorize(void* blas, hipStream_t stream, const double* Z, int n, int d, int m, double amp, double sigma,
+                        double* K, double* alpha, int* info_host) {
+    RocLibs& R = roclibs();
+    DBG("gp_factorize: kernel matrix n=%d d=%d m=%d", n, d, m);
+    hipLaunchKernelGGL(k_gp_matrix, dim3((n + 127) / 128, n), dim3(128), 0, stream, Z, n, d, amp, sigma * sigma, K);
+    HIP_TRY(hipGetLastError());
+    int* info = nullptr;
+    HIP_TRY(hipMalloc(&info, sizeof(int)));
+    int rc = 0;
+    if (R.potrf) {      // GPF_USE_ROCSOLVER=1
+        DBG("gp_factorize: rocsolver dpotrf");
+        rc = R.potrf(blas, ROC_FILL_LOWER, n, K, n, info);
+        if (rc == 0) rc = R.potrs(blas, ROC_FILL_LOWER, n, m, K, n, alpha, n);
+    } else {
+        hipLaunchKernelGGL(k_gp_potrf, dim3(1), dim3(1024), 0, stream, K, n, info);
+        hipLaunchKernelGGL(k_gp_potrs, dim3(1), dim3(1024), 0, stream, K, n, m, alpha);
+    }
+    hipError_t e = hipMemcpyAsync(info_host, info, sizeof(int), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    hipFree(info);
+    if (rc != 0) return fail(GPF_ERR_SOLVER, "rocSOLVER dpotrf/dpotrs returned status " + std::to_string(rc));
+    if (e != hipSuccess) return fail(GPF_ERR_HIP, hipGetErrorString(e));
+    hipLaunchKernelGGL(k_gp_clean_lower, dim3((n + 127) / 128, n), dim3(128), 0, stream, K, n);
+    HIP_TRY(hipGetLastError());
+    return GPF_OK;
+}
+
+extern "C" int gpf_gp_fit(int device, int n, int d, int m, const double* Xn, const double* Yn, double amp,
+                          const double* inv_scale, double sigma, double* L_out, double* alpha_out, double* logdet) {
+    if (!Xn || !Yn || !inv_scale) return fail(GPF_ERR_INVALID, "gpf_gp_fit: null argument");
+    if (n < 1 || d < 1 || d > GP_MAX_D || m < 1 || m > 2) return fail(GPF_ERR_INVALID, "gpf_gp_fit: need n>=1, 1<=d<=4, 1<=m<=2");
+    if (gpf_device_count() == 0) return fail(GPF_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    HIP_TRY(hipSetDevice(device));
+    DBG("gpf_gp_fit: dlopen rocBLAS/rocSOLVER");
+    RocLibs& R = roclibs();
+    if (!R.ok) return fail(GPF_ERR_SOLVER, R.err);
+    DBG("gpf_gp_fit: libraries ready");
+    std::vector<double> Z((size_t)n * d), Ycm((size_t)n * m);
+    for (int i = 0; i < n; ++i) {
+        for (int k = 0; k < d; ++k) Z[(size_t)i * d + k] = Xn[(size_t)i * d + k] * inv_scale[k];
+        for (int o = 0; o < m; ++o) Ycm[(size_t)o * n + i] = Yn[(size_t)i * m + o];
+    }
+    double *dZ = nullptr, *dK = nullptr, *dA = nullptr, *dld = nullptr;
+    void* blas = nullptr;
+    int rc = GPF_OK, info = 0;
+    auto done = [&](int code) {
+        if (dZ) hipFree(dZ);
+        if (dK) hipFree(dK);
+        if (dA) hipFree(dA);
+        if (dld) hipFree(dld);
+        if (blas) R.destroy(blas);
+        return code;
+    };
+    if (hipMalloc(&dZ, Z.size() * 8) != hipSuccess || hipMalloc(&dK, (size_t)n * n * 8) != hipSuccess ||
+        hipMalloc(&dA, Ycm.size() * 8) != hipSuccess || hipMalloc(&dld, 8) != hipSuccess)
+        return done(fail(GPF_ERR_HIP, "gpf_gp_fit: hipMalloc failed"));
+    hipMemcpy(dZ, Z.data(), Z.size() * 8, hipMemcpyHostToDevice);
+    hipMemcpy(dA, Ycm.data(), Ycm.size() * 8, hipMemcpyHostToDevice);
+    DBG("gpf_gp_fit: rocblas_create_handle");
+    if (R.create(&blas) != 0) return done(fail(GPF_ERR_SOLVER, "rocblas_create_handle failed"));
+    DBG("gpf_gp_fit: handle created");
+    rc = gp_factorize(blas, nullptr, dZ, n, d, m, amp, sigma, dK, dA, &info);
+    if (rc != GPF_OK) return done(rc);
+    if (info != 0) return done(fail(GPF_ERR_SOLVER, "gpf_gp_fit: kernel matrix not positive definite (dpotrf info = " + std::to_string(info) + ")"));
+    hipLaunchKernelGGL(k_gp_logdet, dim3(1), dim3(1), 0, 0, dK, n, dld);
+    if (logdet) hipMemcpy(logdet, dld, 8, hipMemcpyDeviceToHost);
+    if (alpha_out) {
+        hipMemcpy(Ycm.data(), dA, Ycm.size() * 8, hipMemcpyDeviceToHost);
+        for (int i = 0; i < n; ++i)
+            for (int o = 0; o < m; ++o) alpha_out[(size_t)i * m + o] = Ycm[(size_t)o * n + i];
+    }
+    if (L_out) {
+        std::vector<double> Lc((size_t)n * n);
+        hipMemcpy(Lc.data(), dK, Lc.size() * 8, hipMemcpyDeviceToHost);
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) L_out[(size_t)i * n + j] = Lc[(size_t)j * n + i];      // row-major out
+    }
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return done(fail(GPF_ERR_HIP, hipGetErrorString(e)));
+    return done(GPF_OK);
+}
+
+extern "C" int gpf_gp_clear_model(gpf_handle* h, int which) {
+    if (!h || which < 0 || which > 2) return fail(GPF_ERR_INVALID, "gpf_gp_clear_model: bad argument");
+    auto& g = h->gp[which];
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (g.Z) hipFree(g.Z);
+    if (g.alpha) hipFree(g.alpha);
+    if (g.L) hipFree(g.L);
+    g.Z = g.alpha = g.L = nullptr;
+    g.set = false;
+    return GPF_OK;
+}
+
+extern "C" int gpf_gp_set_model(gpf_handle* h, int which, int n, int d, int m, const int32_t* dims, const double* x_scale,
+                                const double* Xn, const double* Yn, double amp, const double* inv_scale, double sigma,
+                                double yscale) {
+    if (!h || !dims || !x_scale || !Xn || !Yn || !inv_scale) return fail(GPF_ERR_INVALID, "gpf_gp_set_model: null argument");
+    if (which < 0 || which > 2) return fail(GPF_ERR_INVALID, "gpf_gp_set_model: which must be 0 (press), 1 (shear xz), 2 (shear yz)");
+    if (n < 1 || d < 1 || d > GP_MAX_D) return fail(GPF_ERR_INVALID, "gpf_gp_set_model: need n >= 1 and 1 <= d <= 4");
+    if (m != (which == 0 ? 1 : 2)) return fail(GPF_ERR_INVALID, "gpf_gp_set_model: pressure has 1 output, wall shear 2 (lower, upper)");
+    for (int k = 0; k < d; ++k)
+        if (dims[k] < 0 || dims[k] > 6) return fail(GPF_ERR_INVALID, "gpf_gp_set_model: feature index out of range 0..6");
+    GPF_TRY(gpf_gp_clear_model(h, which));
+    void* blas = nullptr;
+    GPF_TRY(gp_blas(h, &blas));
+    auto& g = h->gp[which];
+    std::vector<double> Z((size_t)n * d), Ycm((size_t)n * m);
+    for (int i = 0; i < n; ++i) {
+        for (int k = 0; k < d; ++k) Z[(size_t)i * d + k] = Xn[(size_t)i * d + k] * inv_scale[k];
+        for (int o = 0; o < m; ++o) Ycm[(size_t)o * n + i] = Yn[(size_t)i * m + o];
+    }
+    HIP_TRY(hipMalloc(&g.Z, Z.size() * 8));
+    HIP_TRY(hipMalloc(&g.alpha, Ycm.size() * 8));
+    HIP_TRY(hipMalloc(&g.L, (size_t)n * n * 8));
+    HIP_TRY(hipMemcpyAsync(g.Z, Z.data(), Z.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(g.alpha, Ycm.data(), Ycm.size() * 8, hipMemcpyHostToDevice, h->stream));
+    int info = 0;
+    GPF_TRY(gp_factorize(blas, h->stream, g.Z, n, d, m, amp, sigma, g.L, g.alpha, &info));
+    if (info != 0) {
+        gpf_gp_clear_model(h, which);
+        return fail(GPF_ERR_SOLVER, "gpf_gp_set_model: kernel matrix not positive definite (dpotrf info = " + std::to_string(info) + ")");
+    }
+    GpModelDev& D = g.dev;
+    D.n = n; D.d = d; D.m = m; D.amp = amp; D.yscale = yscale;
+    for (int k = 0; k < GP_MAX_D; ++k) { D.dims[k] = k < d ? dims[k] : 0; D.fscale[k] = k < d ? inv_scale[k] / x_scale[k] : 0.0; }
+    D.Z = g.Z; D.alpha = g.alpha; D.L = g.L;
+    g.xscale0 = x_scale[0];
+    g.set = true;
+    if (!h->gpvar) {
+        HIP_TRY(hipMalloc(&h->gpvar, (size_t)3 * h->L.plane * 8));
+        HIP_TRY(hipMemsetAsync(h->gpvar, 0, (size_t)3 * h->L.plane * 8, h->stream));
+    }
+    return GPF_OK;
+}
+
+static int gp_scratch(gpf_handle* h, int nblocks) {
+    if (h->gpscratch_n >= nblocks) return GPF_OK;
+    if (h->gpscratch) HIP_TRY(hipFree(h->gpscratch));
+    h->gpscratch = nullptr;
+    HIP_TRY(hipMalloc(&h->gpscratch, ((size_t)nblocks + 8) * 8));
+    h->gpscratch_n = nblocks;
+    return GPF_OK;
+}
+
+static GpFieldArgs gp_field_args(gpf_handle* h, int which, const double* q) {
+    GpFieldArgs a;
+    a.q = q; a.topo = h->topo; a.Ls = h->Ls; a.L = h->L;
+    FieldPtrs F = field_ptrs(h);
+    a.out0 = a.out1 = nullptr;
+    if (which == 0) a.out0 = F.p;
+    else {
+        const int oi = which == 1 ? 4 : 3;          // Voigt xz / yz (stress.py:91)
+        a.out0 = F.lower + (size_t)oi * h->L.plane;
+        a.out1 = F.upper + (size_t)oi * h->L.plane;
+    }
+    a.blockmax = nullptr;
+    return a;
+}
+
+#define GP_DISPATCH_D(d, ...)                                                                           \
+    switch (d) {                                                                                        \
+    case 1: { constexpr int D_ = 1; __VA_ARGS__; } break;                                               \
+    case 2: { constexpr int D_ = 2; __VA_ARGS__; } break;                                               \
+    case 3: { constexpr int D_ = 3; __VA_ARGS__; } break;                                               \
+    default: { constexpr int D_ = 4; __VA_ARGS__; } break;                                              \
+    }
+
+// posterior mean of model `which` on field q into the derived-field planes; with_grad (pressure only):
+// also *c2_out (device) = max_cells d mean/d rho * Yscale / X_scale[0]
+static int gp_launch_mean(gpf_handle* h, int which, const double* q, bool with_grad, double* c2_out) {
+    auto& g = h->gp[which];
+    GPF_TRY(ensure_fields(h));
+    const Layout& L = h->L;
+    const long long ncell = (long long)(L.Nx + 2) * (L.Ny + 2);
+    const int nb = (int)((ncell + 255) / 256);
+    GpFieldArgs a = gp_field_args(h, which, q);
+    if (with_grad) {
+        GPF_TRY(gp_scratch(h, nb));
+        a.blockmax = h->gpscratch;
+        a.out0 = a.out1 = nullptr;
+    }
+    GP_DISPATCH_D(g.dev.d, {
+        if (with_grad) hipLaunchKernelGGL((k_gp_mean<D_, 1, true>), dim3(nb), dim3(256), 0, h->stream, g.dev, a);
+        else if (g.dev.m == 1) hipLaunchKernelGGL((k_gp_mean<D_, 1, false>), dim3(nb), dim3(256), 0, h->stream, g.dev, a);
+        else hipLaunchKernelGGL((k_gp_mean<D_, 2, false>), dim3(nb), dim3(256), 0, h->stream, g.dev, a);
+    });
+    HIP_TRY(hipGetLastError());
+    if (with_grad) {
+        // dmean/dx_0 in normalised units carries s_0 = inv_scale_0: fscale_0 * X_scale_0; then * Yscale / X_scale_0
+        const double scale = g.dev.fscale[0] * g.dev.yscale;
+        hipLaunchKernelGGL(k_gp_maxreduce, dim3(1), dim3(256), 0, h->stream, h->gpscratch, nb, scale, c2_out);
+        HIP_TRY(hipGetLastError());
+    }
+    return GPF_OK;
+}
+
+extern "C" int gpf_gp_variance(gpf_handle* h, int which, int on_open_step, double* max_var) {
+    if (!h || which < 0 || which > 2) return fail(GPF_ERR_INVALID, "gpf_gp_variance: bad argument");
+    auto& g = h->gp[which];
+    if (!g.set) return fail(GPF_ERR_STATE, "gpf_gp_variance: model not set");
+    if (on_open_step && !h->step_open) return fail(GPF_ERR_STATE, "gpf_gp_variance: no open step");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    void* blas = nullptr;
+    GPF_TRY(gp_blas(h, &blas));
+    RocLibs& R = roclibs();
+    const Layout& L = h->L;
+    int par = 0;
+    GPF_TRY(current_parity(h, &par));
+    const double* q = on_open_step ? h->q[par ^ 1] : h->q[par];
+    const long long ncell = (long long)(L.Nx + 2) * (L.Ny + 2);
+    const int n = g.dev.n;
+    const long long tile = std::max<long long>(256, std::min<long long>(ncell, (64ll << 20) / (8ll * n)));   // <= 64 MiB of Ks
+    if (h->gptile_doubles < (size_t)(tile * n)) {
+        if (h->gptile) HIP_TRY(hipFree(h->gptile));
+        h->gptile = nullptr;
+        HIP_TRY(hipMalloc(&h->gptile, (size_t)(tile * n) * 8));
+        h->gptile_doubles = (size_t)(tile * n);
+    }
+    const int nb_total = (int)((ncell + 255) / 256) + 8;
+    GPF_TRY(gp_scratch(h, nb_total));
+    GpFieldArgs a = gp_field_args(h, which, q);
+    double* var_plane = h->gpvar + (size_t)which * L.plane;
+    const double one = 1.0;
+    int nbm = 0;
+    for (long long c0 = 0; c0 < ncell; c0 += tile) {
+        const int ncols = (int)std::min<long long>(tile, ncell - c0);
+        GP_DISPATCH_D(g.dev.d, {
+            hipLaunchKernelGGL((k_gp_ks_tile<D_>), dim3((n + 255) / 256, ncols), dim3(256), 0, h->stream, g.dev, a, c0, ncols, h->gptile);
+        });
+        HIP_TRY(hipGetLastError());
+        if (R.trsm(blas, ROC_SIDE_LEFT, ROC_FILL_LOWER, ROC_OP_NONE, ROC_DIAG_NON_UNIT, n, ncols, &one, g.L, n, h->gptile, n) != 0)
+            return fail(GPF_ERR_SOLVER, "rocblas_dtrsm failed");
+        const int nb = (ncols + 255) / 256;
+        hipLaunchKernelGGL(k_gp_var_tile, dim3(nb), dim3(256), 0, h->stream, h->gptile, n, ncols, g.dev.amp,
+                           g.dev.yscale * g.dev.yscale, c0, L, var_plane, h->gpscratch + nbm);
+        HIP_TRY(hipGetLastError());
+        nbm += nb;
+    }
+    double* res = h->gpscratch + h->gpscratch_n;
+    hipLaunchKernelGGL(k_gp_maxreduce, dim3(1), dim3(256), 0, h->stream, h->gpscratch, nbm, 1.0, res);
+    HIP_TRY(hipGetLastError());
+    double mv = 0.0;
+    HIP_TRY(hipMemcpyAsync(&mv, res, 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (max_var) *max_var = mv;
+    return GPF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the unfused step in pieces, for closures that need the host between stages (GP + active learning)
+// ---------------------------------------------------------------------------------------------
+extern "C" int gpf_open_step(gpf_handle* h) {
+    if (!h) return fail(GPF_ERR_INVALID, "null handle");
+    if (!h->pre_run_done) return fail(GPF_ERR_STATE, "gpf_open_step: call gpf_pre_run first");
+    if (h->step_open) return fail(GPF_ERR_STATE, "gpf_open_step: a step is already open");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const Layout& L = h->L;
+    GPF_TRY(ensure_fields(h));
+    if (!h->work) HIP_TRY(hipMalloc(&h->work, (size_t)9 * L.plane * sizeof(double)));
+    StepState s;
+    GPF_TRY(read_state(h, s));
+    if (s.invalid) return fail(GPF_ERR_STATE, "gpf_open_step: the state is invalid (rolled back); nothing to advance");
+    h->open_parity = s.parity;
+    hipLaunchKernelGGL(k_copy3, dim3(blocks_for(3 * L.plane)), dim3(256), 0, h->stream, h->q[s.parity], h->q[s.parity ^ 1], 3 * L.plane);
+    HIP_TRY(hipGetLastError());
+    h->step_open = true;
+    h->host_step = s.step; h->next_step = s.step;
+    return GPF_OK;
+}
+
+extern "C" int gpf_stage_closures(gpf_handle* h) {
+    if (!h || !h->step_open) return fail(GPF_ERR_STATE, "gpf_stage_closures: no open step");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    return launch_fields(h, h->q[h->open_parity ^ 1]);
+}
+
+extern "C" int gpf_stage_advance(gpf_handle* h, int stage) {
+    if (!h || !h->step_open) return fail(GPF_ERR_STATE, "gpf_stage_advance: no open step");
+    if (stage != 0 && stage != 1) return fail(GPF_ERR_INVALID, "gpf_stage_advance: stage must be 0 (predictor) or 1 (corrector)");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const Layout& L = h->L;
+    double* q = h->q[h->open_parity ^ 1];
+    const long long n = (long long)(L.Nx + 2) * (L.Ny + 2);
+    const int nb = blocks_for(n);
+    double *fx = h->work, *fy = h->work + 3 * L.plane, *src = h->work + 6 * L.plane;
+    FieldPtrs F = field_ptrs(h);
+    const int mc = h->cfg.mc_order;
+    const int sw = mc == 0 ? ((h->host_step % 2 == 0) ? 1 : -1) : mc;
+    const int first = ((sw + 1) / 2) ? 1 : -1;
+    const int dir = stage == 0 ? first : -first;
+    hipLaunchKernelGGL(k_fluxdiff, dim3(nb), dim3(256), 0, h->stream, q, F.p, F.tau, dir, fx, fy, L);
+    hipLaunchKernelGGL(k_source, dim3(nb), dim3(256), 0, h->stream, q, h->topo, F.tau, F.lower, F.upper, src, L);
+    hipLaunchKernelGGL(k_axpy, dim3(nb), dim3(256), 0, h->stream, q, fx, fy, src, h->st, h->cfg.dx, h->cfg.dy, L);
+    hipLaunchKernelGGL(k_bc_x, dim3((L.Ny + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
+    hipLaunchKernelGGL(k_bc_y, dim3((L.Nx + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
+    HIP_TRY(hipGetLastError());
+    return GPF_OK;
+}
+
+extern "C" int gpf_close_step(gpf_handle* h, gpf_scalars_t* out) {
+    if (!h || !h->step_open) return fail(GPF_ERR_STATE, "gpf_close_step: no open step");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const Layout& L = h->L;
+    double* q = h->q[h->open_parity ^ 1];
+    const double* q0 = h->q[h->open_parity];
+    const long long n = (long long)(L.Nx + 2) * (L.Ny + 2);
+    hipLaunchKernelGGL(k_average, dim3(blocks_for(n)), dim3(256), 0, h->stream, q, q0, L);
+    ScalarPartial* pre = h->spart + h->nspart;
+    ScalarPartial* post = h->spart + h->nspart + 1;
+    GPF_TRY(launch_scalars(h, q, pre));                 // validity of the averaged field (problem.py:565)
+    hipLaunchKernelGGL(k_bc_x, dim3((L.Ny + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
+    hipLaunchKernelGGL(k_bc_y, dim3((L.Nx + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
+    GPF_TRY(launch_scalars(h, q, post));                // scalars after the ghost update (problem.py:576-578)
+    hipLaunchKernelGGL(k_commit_unfused, dim3(1), dim3(1), 0, h->stream, h->st, pre, post);
+    HIP_TRY(hipGetLastError());
+    h->step_open = false;
+    StepState s;
+    GPF_TRY(read_state(h, s));
+    h->host_step = s.step; h->next_step = s.step;
+    if (out) fill_scalars(s, nullptr, 0.0, out);
     return GPF_OK;
 }

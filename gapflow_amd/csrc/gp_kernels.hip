@@ -1,0 +1,296 @@
+// Gaussian-process surrogate closure on the GPU (GaPFlow/models/gp.py, tinygp semantics).
+//
+//   k(x,x') = A (1 + sqrt3 r) exp(-sqrt3 r),  r = || s o (x - x') ||_2      gp.py:598-603 (Matern-3/2, ARD)
+//   K = k(X,X) + sigma^2 I = L L^T                                           tinygp GaussianProcess(diag=yerr^2)
+//   alpha = K^-1 Y ; mean(x*) = sum_i alpha_i k(x_i, x*)                     gp.py:525-535
+//   var(x*) = A - || L^-1 k(X, x*) ||^2                                      gp.py:509-522
+//   d mean / d x*_0 = sum_i alpha_i 3 A s_0 (s_0 (x_i0 - x*_0)) exp(-sqrt3 r)   stress.py:533-537
+//
+// The reference materialises Ks = k(X_train, X_test) for all cells (N_train x cells: 17 GB per GP
+// at 2048^2 with 512 training points, gp.py:516,532).  Here the mean is a fused kernel: training
+// inputs and alpha sit in LDS, every thread owns one cell and streams over the training set --
+// fp64 VALU/transcendental bound, no HBM traffic beyond the fields themselves.  Only the variance
+// needs a dense solve: cells are processed in tiles, Ks of a tile is built, rocBLAS dtrsm (the one
+// MFMA-shaped operation of the path) forms L^-1 Ks and a column-norm kernel finishes.
+// The Cholesky factorisation and alpha come from the in-library k_gp_potrf / k_gp_potrs (default) or from
+// rocSOLVER dpotrf / dpotrs (GPF_USE_ROCSOLVER=1); rocBLAS / rocSOLVER are dlopen'ed so that a process
+// which also hosts PyTorch binds to the copies already mapped.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdlib.h>
+#include "device_types.hpp"
+
+namespace gpf {
+
+constexpr int GP_MAX_D = 4;
+constexpr int GP_CHUNK = 512;        // training points staged in LDS per pass
+
+struct GpModelDev {
+    int n, d, m;
+    int dims[GP_MAX_D];             // feature index of each active dimension: 0..2 q, 3..5 topography, 6 extra
+    double fscale[GP_MAX_D];        // inv_scale / X_scale: raw feature -> kernel coordinate
+    double amp, yscale;
+    const double* Z;                // [n][d] training inputs in kernel coordinates (X_norm * inv_scale)
+    const double* alpha;            // [m][n]
+    const double* L;                // [n][n] column-major lower Cholesky factor
+};
+
+struct GpFieldArgs {
+    const double* q; const double* topo; const double* Ls;
+    Layout L;
+    double* out0; double* out1;     // output planes (already offset to the component), out1 only for m == 2
+    double* blockmax;               // per-block max of d mean/d x_0 (WITH_GRAD) or nullptr
+};
+
+__device__ __forceinline__ double gp_feature(const GpFieldArgs& a, int f, long long o) {
+    if (f < 3) return a.q[o + f * a.L.plane];
+    if (f < 6) return a.topo[o + (f - 3) * a.L.plane];
+    return a.Ls ? a.Ls[o] : 0.0;
+}
+
+// K (column-major n x n) = k(Z, Z) + sigma^2 I, with Z already in kernel coordinates
+__global__ void k_gp_matrix(const double* Z, int n, int d, double amp, double sigma2, double* K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (i >= n) return;
+    double r2 = 0.0;
+    for (int k = 0; k < d; ++k) {
+        const double t = Z[i * d + k] - Z[j * d + k];
+        r2 += t * t;
+    }
+    const double r = sqrt(3.0 * r2);                  // sqrt3 * r
+    K[i + (long long)j * n] = amp * (1.0 + r) * exp(-r) + (i == j ? sigma2 : 0.0);
+}
+
+// posterior mean (and optionally d mean/d x_0) at every cell of the grid incl. ghost cells
+template <int D, int M, bool WITH_GRAD>
+__global__ __launch_bounds__(256) void k_gp_mean(const GpModelDev g, const GpFieldArgs a) {
+    __shared__ double sZ[GP_CHUNK * D];
+    __shared__ double sA[GP_CHUNK * M];
+    __shared__ double sred[4];
+    const long long w = a.L.Ny + 2, ncell = (long long)(a.L.Nx + 2) * w;
+    const long long cell = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const bool active = cell < ncell;
+    long long o = 0;
+    double z[D];
+    if (active) {
+        o = a.L.at((int)(cell / w), (int)(cell % w));
+        for (int k = 0; k < D; ++k) z[k] = gp_feature(a, g.dims[k], o) * g.fscale[k];
+    } else {
+        for (int k = 0; k < D; ++k) z[k] = 0.0;
+    }
+    double acc[M], gacc = 0.0;
+    for (int k = 0; k < M; ++k) acc[k] = 0.0;
+    for (int base = 0; base < g.n; base += GP_CHUNK) {
+        const int cnt = min(GP_CHUNK, g.n - base);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt * D; t += blockDim.x) sZ[t] = g.Z[(long long)base * D + t];
+        for (int t = threadIdx.x; t < cnt * M; t += blockDim.x) sA[t] = g.alpha[(long long)(t / cnt) * g.n + base + (t % cnt)];
+        __syncthreads();
+        for (int i = 0; i < cnt; ++i) {
+            double r2 = 0.0, d0 = 0.0;
+            for (int k = 0; k < D; ++k) {
+                const double t = sZ[i * D + k] - z[k];
+                if (k == 0) d0 = t;
+                r2 += t * t;
+            }
+            const double r = sqrt(3.0 * r2);
+            const double e = exp(-r);
+            const double kv = (1.0 + r) * e;
+            for (int k = 0; k < M; ++k) acc[k] += sA[k * cnt + i] * kv;
+            if (WITH_GRAD) gacc += sA[i] * d0 * e;
+        }
+    }
+    if (active) {
+        if (a.out0) a.out0[o] = g.amp * acc[0] * g.yscale;
+        if (M > 1 && a.out1) a.out1[o] = g.amp * acc[M - 1] * g.yscale;
+    }
+    if (WITH_GRAD) {
+        // d mean/d x_0 in normalised units: 3 A s_0 sum_i alpha_i (z_i0 - z*_0) e_i ; s_0 = fscale * X_scale
+        double v = active ? 3.0 * g.amp * gacc : -__builtin_inf();
+        for (int s = 32; s >= 1; s >>= 1) v = nanmax(v, __shfl_down(v, s));
+        if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 1; i < (int)(blockDim.x >> 6); ++i) v = nanmax(v, sred[i]);
+            a.blockmax[blockIdx.x] = v;
+        }
+    }
+}
+
+__global__ void k_gp_maxreduce(const double* in, int n, double scale, double* out) {
+    __shared__ double s[4];
+    double v = -__builtin_inf();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v = nanmax(v, in[i]);
+    for (int k = 32; k >= 1; k >>= 1) v = nanmax(v, __shfl_down(v, k));
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) v = nanmax(v, s[i]);
+        out[0] = v * scale;
+    }
+}
+
+// Ks tile: column j = k(Z, z*_j) for cells [cell0, cell0 + ncols), column-major n x ncols
+template <int D>
+__global__ __launch_bounds__(256) void k_gp_ks_tile(const GpModelDev g, const GpFieldArgs a, long long cell0, int ncols,
+                                                    double* Ks) {
+    const long long w = a.L.Ny + 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // training point
+    const int j = blockIdx.y;                                 // column of the tile
+    if (i >= g.n || j >= ncols) return;
+    const long long cell = cell0 + j;
+    const long long o = a.L.at((int)(cell / w), (int)(cell % w));
+    double r2 = 0.0;
+    for (int k = 0; k < D; ++k) {
+        const double t = g.Z[(long long)i * D + k] - gp_feature(a, g.dims[k], o) * g.fscale[k];
+        r2 += t * t;
+    }
+    const double r = sqrt(3.0 * r2);
+    Ks[i + (long long)j * g.n] = g.amp * (1.0 + r) * exp(-r);
+}
+
+// var_j = (A - sum_i V_ij^2) * yscale^2 for a solved tile V = L^-1 Ks; per-block max for the AL criterion
+__global__ __launch_bounds__(256) void k_gp_var_tile(const double* V, int n, int ncols, double amp, double yscale2,
+                                                     long long cell0, Layout L, double* var_plane, double* blockmax) {
+    __shared__ double sred[4];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double out = -__builtin_inf();
+    if (j < ncols) {
+        const double* col = V + (long long)j * n;
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += col[i] * col[i];
+        out = (amp - s) * yscale2;
+        const long long w = L.Ny + 2, cell = cell0 + j;
+        var_plane[L.at((int)(cell / w), (int)(cell % w))] = out;
+    }
+    for (int s = 32; s >= 1; s >>= 1) out = nanmax(out, __shfl_down(out, s));
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = out;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) out = nanmax(out, sred[i]);
+        blockmax[blockIdx.x] = out;
+    }
+}
+
+// In-library Cholesky factorisation K = L L^T (lower, in place, column-major) for the few-hundred-point
+// training sets of the surrogates: one 1024-thread workgroup, right-looking, the matrix stays in L2
+// (512^2 doubles = 2 MB).  *info = 0, or j+1 if the leading minor of order j+1 is not positive definite
+// (LAPACK dpotrf convention).  rocSOLVER's dpotrf is the alternative (GPF_USE_ROCSOLVER=1); its 930 MB
+// shared object costs ~100 s to map on a cold node, which no 45-MFLOP factorisation can repay.
+__global__ __launch_bounds__(1024) void k_gp_potrf(double* A, int n, int* info) {
+    __shared__ double diag;
+    __shared__ int bad;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int tk = tid >> 5, ti = tid & 31;
+    if (tid == 0) bad = 0;
+    for (int j = 0; j < n; ++j) {
+        __syncthreads();
+        if (tid == 0) {
+            double d = A[j + (long long)j * n];
+            if (!(d > 0.0)) { bad = j + 1; d = 1.0; } else d = sqrt(d);
+            A[j + (long long)j * n] = d;
+            diag = d;
+        }
+        __syncthreads();
+        if (bad) break;
+        const double inv = 1.0 / diag;
+        for (int i = j + 1 + tid; i < n; i += T) A[i + (long long)j * n] *= inv;
+        __syncthreads();
+        const double* col = A + (long long)j * n;
+        for (int kk = j + 1; kk < n; kk += 32) {
+            const int k = kk + tk;
+            for (int ii = kk; ii < n; ii += 32) {
+                const int i = ii + ti;
+                if (k < n && i < n && i >= k) A[i + (long long)k * n] -= col[i] * col[k];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) *info = bad;
+}
+
+// Solves L L^T X = B in place for nrhs right-hand sides (B column-major n x nrhs), one workgroup
+__global__ __launch_bounds__(1024) void k_gp_potrs(const double* Lm, int n, int nrhs, double* B) {
+    __shared__ double piv;
+    const int tid = threadIdx.x, T = blockDim.x;
+    for (int r = 0; r < nrhs; ++r) {
+        double* b = B + (long long)r * n;
+        for (int j = 0; j < n; ++j) {                  // L y = b
+            __syncthreads();
+            if (tid == 0) { piv = b[j] / Lm[j + (long long)j * n]; b[j] = piv; }
+            __syncthreads();
+            const double y = piv;
+            for (int i = j + 1 + tid; i < n; i += T) b[i] -= Lm[i + (long long)j * n] * y;
+        }
+        for (int j = n - 1; j >= 0; --j) {             // L^T x = y
+            __syncthreads();
+            if (tid == 0) { piv = b[j] / Lm[j + (long long)j * n]; b[j] = piv; }
+            __syncthreads();
+            const double x = piv;
+            for (int i = tid; i < j; i += T) b[i] -= Lm[j + (long long)i * n] * x;
+        }
+    }
+}
+
+// log det K = 2 sum log L_ii
+__global__ void k_gp_logdet(const double* Lm, int n, double* out) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += log(Lm[i + (long long)i * n]);
+    out[0] = 2.0 * s;
+}
+
+// zero the strict upper triangle so L can be handed out as a clean lower-triangular matrix
+__global__ void k_gp_clean_lower(double* Lm, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (i < n && i < j) Lm[i + (long long)j * n] = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rocBLAS / rocSOLVER through dlopen (no link-time dependency)
+// ---------------------------------------------------------------------------------------------
+struct RocLibs {
+    typedef int (*create_t)(void**);
+    typedef int (*destroy_t)(void*);
+    typedef int (*set_stream_t)(void*, hipStream_t);
+    typedef int (*potrf_t)(void*, int, int, double*, int, int*);
+    typedef int (*potrs_t)(void*, int, int, int, double*, int, double*, int);
+    typedef int (*trsm_t)(void*, int, int, int, int, int, int, const double*, const double*, int, double*, int);
+    create_t create = nullptr; destroy_t destroy = nullptr; set_stream_t set_stream = nullptr;
+    potrf_t potrf = nullptr; potrs_t potrs = nullptr; trsm_t trsm = nullptr;
+    bool ok = false;
+    const char* err = "";
+};
+
+// rocBLAS enum values (rocblas-types.h): fill lower = 122, side left = 141, op none = 111, diag non-unit = 131
+enum { ROC_FILL_LOWER = 122, ROC_SIDE_LEFT = 141, ROC_OP_NONE = 111, ROC_DIAG_NON_UNIT = 131 };
+
+inline RocLibs& roclibs() {
+    static RocLibs R;
+    static bool tried = false;
+    if (tried) return R;
+    tried = true;
+    void* hb = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
+    if (!hb) hb = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!hb) hb = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!hb) { R.err = "could not dlopen rocBLAS"; return R; }
+    R.create = (RocLibs::create_t)dlsym(hb, "rocblas_create_handle");
+    R.destroy = (RocLibs::destroy_t)dlsym(hb, "rocblas_destroy_handle");
+    R.set_stream = (RocLibs::set_stream_t)dlsym(hb, "rocblas_set_stream");
+    R.trsm = (RocLibs::trsm_t)dlsym(hb, "rocblas_dtrsm");
+    R.ok = R.create && R.destroy && R.set_stream && R.trsm;
+    if (!R.ok) { R.err = "rocBLAS symbols missing"; return R; }
+    const char* use = getenv("GPF_USE_ROCSOLVER");
+    if (use && use[0] == '1') {
+        void* hs = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
+        if (!hs) hs = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!hs) hs = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+        if (hs) {
+            R.potrf = (RocLibs::potrf_t)dlsym(hs, "rocsolver_dpotrf");
+            R.potrs = (RocLibs::potrs_t)dlsym(hs, "rocsolver_dpotrs");
+        }
+        if (!R.potrf || !R.potrs) { R.ok = false; R.err = "GPF_USE_ROCSOLVER=1 but rocSOLVER could not be loaded"; }
+    }
+    return R;
+}
+
+}  // namespace gpf

@@ -1,10 +1,376 @@
-"""Gaussian-process surrogate closure (GaPFlow/models/gp.py) -- entry points used by Problem."""
+"""Gaussian-process surrogate closures: host-side control flow around the device GP kernels.
+
+Mirrors (reference paths):
+  GaPFlow/models/gp.py:46-603      GaussianProcessSurrogate (train / infer / active-learning loop)
+  GaPFlow/models/stress.py:93-109, 195-287, 497-598   which features, outputs and scales each model uses
+  GaPFlow/db.py:46-369             training database (arrays X (N,7), Y (N,13), Yerr (N,13), max-abs normalisers)
+  GaPFlow/md/mock.py:32-107        Mock MD runner: fixed-form laws + noise
+
+What runs where.  Per time step the posterior mean (every stage), the predictive variance and the GP
+sound speed are HIP kernels (csrc/gp_kernels.hip) fed by a device-resident Cholesky factor (gpf_gp_set_model:
+in-library blocked Cholesky by default, rocSOLVER dpotrf/dpotrs with GPF_USE_ROCSOLVER=1; the variance solve is
+rocBLAS dtrsm).  Hyper-parameter training -- a handful of marginal-likelihood evaluations on <= a few
+hundred points, run only when the database grows (gp.py:461-465) -- stays on the host with SciPy BFGS, the
+optimiser the reference reaches through jaxopt.ScipyMinimize (gp.py:320-321).  Persistence of training data
+in dtool datasets and the LAMMPS runners are out of scope; the database lives in memory.
+
+Deliberate deviation: jax's PRNG streams (db.py:326-336, mock.py:82-88) cannot be reproduced without jax;
+NumPy's default_rng with the same seeds is used instead.
+"""
+import ctypes as C
+from datetime import datetime
+
+import numpy as np
+from scipy.linalg import cho_factor, cho_solve
+from scipy.optimize import minimize
+from scipy.stats import qmc
+
+from . import _lib
+
+SQRT3 = np.sqrt(3.0)
 
 
-def attach_surrogates(*a, **k):
-    raise NotImplementedError("the GP surrogate closure is being brought up on the HIP path; "
-                              "fixed-form EOS problems run today")
+# ---------------------------------------------------------------------------------------------
+# training objective (host): -sum_o log N(Y_o | 0, K),  K = A (1 + sqrt3 r) exp(-sqrt3 r) + sigma^2 I
+# ---------------------------------------------------------------------------------------------
+def neg_log_likelihood(theta, X, Y, sigma):
+    """Value and gradient w.r.t. theta = [log_amp, log_scale_1..d] (gp.py:307-318, 598-603)."""
+    n, m = Y.shape
+    amp, inv_scale = np.exp(theta[0]), np.exp(-theta[1:])
+    sd = (X[:, None, :] - X[None, :, :]) * inv_scale
+    r = np.sqrt(np.sum(sd * sd, axis=-1))
+    E = np.exp(-SQRT3 * r)
+    Kf = amp * (1.0 + SQRT3 * r) * E
+    try:
+        c = cho_factor(Kf + sigma**2 * np.eye(n), lower=True)
+    except np.linalg.LinAlgError:
+        return 1e300, np.zeros_like(theta)
+    alpha = cho_solve(c, Y)
+    logdet = 2.0 * np.sum(np.log(np.diag(c[0])))
+    f = 0.5 * np.sum(Y * alpha) + 0.5 * m * logdet + 0.5 * m * n * np.log(2 * np.pi)
+    W = alpha @ alpha.T - m * cho_solve(c, np.eye(n))
+    g = np.empty_like(theta)
+    g[0] = -0.5 * np.sum(W * Kf)
+    for j in range(len(theta) - 1):
+        g[1 + j] = -0.5 * np.sum(W * (3.0 * amp * E * sd[:, :, j]**2))
+    return f, g
+
+
+# ---------------------------------------------------------------------------------------------
+# Mock MD runner and in-memory database
+# ---------------------------------------------------------------------------------------------
+class Mock:
+    """Stand-in for an MD run: the fixed-form laws at one state point plus a fixed pseudo-random offset
+    (md/mock.py:81-107).  The laws are evaluated by the device closure kernel on a one-cell problem."""
+
+    name = 'mock'
+    is_mock = True
+
+    def __init__(self, prop, geo, gp):
+        self.noise = (gp['press']['obs_stddev'] if gp['press_gp'] else 0.,
+                      gp['shear']['obs_stddev'] if gp['shear_gp'] else 0.)
+        self.prop, self.geo = prop, geo
+        self.params = dict(prop)
+        self._eval = None
+
+    def _evaluator(self):
+        if self._eval is None:
+            from .problem import Problem
+            grid = {'Nx': 1, 'Ny': 1, 'dx': 1., 'dy': 1., 'Lx': 1., 'Ly': 1., 'dim': 0}
+            for side in ('xE', 'xW', 'yS', 'yN'):
+                grid[f'bc_{side}_P'], grid[f'bc_{side}_D'], grid[f'bc_{side}_N'] = [True] * 3, [False] * 3, [False] * 3
+            geo = dict(self.geo, type='inclined', hmin=1., hmax=1., flip=False)
+            numerics = {'tol': 1e-6, 'max_it': 1, 'dt': 1e-12, 'adaptive': False, 'CFL': 0.5, 'MC_order': 1}
+            prop = {k: v for k, v in self.prop.items() if k not in ('piezo', 'thinning')}
+            prop.setdefault('elastic', {'enabled': False})
+            self._eval = Problem({'output': '', 'write_freq': 1, 'use_tstamp': False, 'silent': True}, grid, numerics,
+                                 prop, geo)
+        return self._eval
+
+    def run(self, X, tag=None):
+        """X: 7 features [rho, jx, jy, h, dh/dx, dh/dy, extra] -> (Y (13,), Yerr (13,))."""
+        ev = self._evaluator()
+        X = np.asarray(X, float)
+        ev.q[...] = X[:3, None, None]
+        ev.topo.full[:3] = X[3:6, None, None]
+        ev._upload_topo()
+        ev._extra[...] = X[6]
+        ev._upload(_lib.FIELD_EXTRA, ev._extra)
+        ev._closures_stale = True
+        p = ev._derived(_lib.FIELD_PRESSURE)[0, 1, 1]
+        bot = ev._derived(_lib.FIELD_WALL_LOWER)[:, 1, 1]
+        top = ev._derived(_lib.FIELD_WALL_UPPER)[:, 1, 1]
+        rng = np.random.default_rng(123)                # one fixed draw per call, like jr.key(123) in mock.py:82
+        noise_p, noise_s0, noise_s1 = rng.standard_normal(3) * np.array([self.noise[0], self.noise[1], self.noise[1]])
+        Y = np.concatenate([[p + noise_p], bot + noise_s0, top + noise_s1])
+        s = self.noise[1]
+        Ye = np.array([self.noise[0], 0., 0., 0., s, s, 0., 0., 0., 0., s, s, 0.])
+        return Y, Ye
+
+
+class Database:
+    """Training data of all surrogates (db.py:46-369), in memory."""
+
+    def __init__(self, md, db, num_extra_features=1):
+        self._md, self._db = md, db
+        self._num_features = 6 + num_extra_features
+        self._Xtrain = np.empty((0, self._num_features))
+        self._Ytrain = np.empty((0, 13))
+        self._Ytrain_err = np.empty((0, 13))
+        self._X_scale = np.ones(self._num_features)
+        self._Y_scale = np.ones(13)
+        self.output_path = None
+
+    config = property(lambda self: self._db)
+    md_config = property(lambda self: self._md.params)
+    size = property(lambda self: self._Xtrain.shape[0])
+    num_features = property(lambda self: self._num_features)
+    has_mock_md = property(lambda self: self._md.is_mock)
+    X_scale = property(lambda self: self._X_scale)
+    Y_scale = property(lambda self: self._Y_scale)
+    Xtrain = property(lambda self: self._Xtrain / self._X_scale)
+    Ytrain = property(lambda self: self._Ytrain / self._Y_scale)
+    Ytrain_err = property(lambda self: self._Ytrain_err / self._Y_scale)
+
+    @staticmethod
+    def _normalizer(x):
+        return np.maximum(np.max(np.abs(x), axis=0), 1e-12)          # db.py:264-266
+
+    def set_arrays(self, X, Y, Yerr):
+        """Load a ready-made training set (replaces dtool persistence, db.py:83-103)."""
+        self._Xtrain, self._Ytrain, self._Ytrain_err = (np.array(a, float) for a in (X, Y, Yerr))
+        self._X_scale, self._Y_scale = self._normalizer(self._Xtrain), self._normalizer(self._Ytrain)
+
+    def initialize(self, Xtest, dim=1):
+        """Fill up to init_size points around the mean state (db.py:278-341)."""
+        db = self._db
+        nsample = db['init_size'] - self.size
+        if nsample <= 0:
+            return
+        print(f"Database contains less than {db['init_size']} MD runs.")
+        if dim == 1:
+            flux, active = np.mean(Xtest[:, 1]), [0, 1]
+        else:
+            flux, active = np.hypot(np.mean(Xtest[:, 1]), np.mean(Xtest[:, 2])), [0, 1, 2]
+        rho, w = np.mean(Xtest[:, 0]), db['init_width']
+        lo = np.array([(1.0 - w) * rho, 0.5 * flux, -0.5 * flux])[active]
+        hi = np.array([(1.0 + w) * rho, 1.5 * flux, 0.5 * flux])[active]
+        rng = np.random.default_rng(db['init_seed'])
+        if db['init_method'] == 'rand':
+            samples = rng.uniform(lo, hi, size=(nsample, len(active)))
+        elif db['init_method'] == 'lhc':
+            samples = qmc.scale(qmc.LatinHypercube(d=len(active), seed=rng).random(n=nsample), lo, hi)
+        else:
+            m = int(np.ceil(np.log2(nsample)))
+            samples = qmc.scale(qmc.Sobol(d=len(active), seed=rng).random_base2(m=m), lo, hi)
+            nsample = samples.shape[0]
+        choice = rng.choice(Xtest.shape[0], size=nsample, replace=False)
+        if len(active) == 2:
+            samples = np.hstack([samples, np.zeros((nsample, 1))])
+        self.add_data(np.column_stack([samples, Xtest[choice, 3:]]))
+
+    def add_data(self, Xnew):
+        for X in np.atleast_2d(Xnew):
+            Y, Ye = self._md.run(X, self.size + 1)
+            self._Xtrain = np.vstack([self._Xtrain, X])
+            self._Ytrain = np.vstack([self._Ytrain, Y])
+            self._Ytrain_err = np.vstack([self._Ytrain_err, Ye])
+            self._X_scale, self._Y_scale = self._normalizer(self._Xtrain), self._normalizer(self._Ytrain)
 
 
 def make_database(input_dict):
-    raise NotImplementedError("db/gp sections: GP surrogate closure not wired into Problem yet")
+    """problem.py:223-249: a `db` section without `md` attaches the Mock runner."""
+    if input_dict.get('md') is not None:
+        raise NotImplementedError("LAMMPS MD runners (GaPFlow/md/) are outside the scope of the MI355X hot path")
+    gp = input_dict.get('gp')
+    if gp is None:
+        raise IOError("a `db` section needs a `gp` section")
+    return Database(Mock(input_dict['properties'], input_dict['geometry'], gp), input_dict['db'])
+
+
+# ---------------------------------------------------------------------------------------------
+# one surrogate model (pressure, wall shear xz, wall shear yz)
+# ---------------------------------------------------------------------------------------------
+class Surrogate:
+    """Host half of GaussianProcessSurrogate for one closure; the device half is gpf_gp_* ."""
+
+    WHICH = {'zz': 0, 'xz': 1, 'yz': 2}
+
+    def __init__(self, problem, name, cfg, database):
+        self._p, self.name, self.database = problem, name, database
+        self.which = self.WHICH[name]
+        self.is_gp_model = True
+        if name == 'zz':
+            self.active_dims = list(cfg.get('active_dims', [0, 3]))                  # stress.py:498
+            self._cols = [0]
+        else:
+            key, default = ('active_dims_x', [0, 1, 3]) if name == 'xz' else ('active_dims_y', [0, 2, 3])
+            self.active_dims = list(cfg.get(key, default))                           # stress.py:94-95
+            oi = 4 if name == 'xz' else 3
+            self._cols = [oi + 1, oi + 7]                                            # stress.py:214-215
+        self.atol, self.rtol = cfg['atol'], cfg['rtol']
+        self.max_steps, self.pause_steps = cfg['max_steps'], cfg['pause_steps']
+        self.use_active_learning = cfg['active_learning']
+        self._step, self._pause, self.last_fit_train_size = 0, 0, 0
+        self.optimise = True            # False: keep the initial hyper-parameters (timing runs, conditioning tests)
+        self.theta = None
+        self.maximum_variance = np.inf
+        self.variance_tol = 0.0
+        self._var_valid = False
+        ref = datetime.now()
+        self.cumtime_train = self.cumtime_infer = ref - ref
+        self.history = {k: [] for k in ('step', 'database_size', 'variance', 'obs_stddev', 'maximum_variance', 'variance_tol')}
+        for li in self.active_dims:
+            self.history[f'lengthscale_{li}'] = []
+
+    # -- training data views (stress.py:199-258, 546-569) ----------------------------------
+    @property
+    def Xtrain(self):
+        return self.database.Xtrain[:self.last_fit_train_size, self.active_dims]
+
+    @property
+    def Yscale(self):
+        return self.database.Y_scale[0] if self.name == 'zz' else np.max(self.database.Y_scale[self._cols])
+
+    @property
+    def Ytrain(self):
+        return self.database._Ytrain[:self.last_fit_train_size][:, self._cols] / self.Yscale
+
+    @property
+    def Yerr(self):
+        n = self.last_fit_train_size
+        if self.name == 'zz':
+            return float(np.mean(self.database.Ytrain_err[:n, 0]))
+        return float(np.mean(self.database._Ytrain_err[:n][:, self._cols] / self.Yscale))
+
+    obs_stddev = property(lambda self: self.Yerr)
+    kernel_variance = property(lambda self: float(np.exp(self.theta[0])))
+    kernel_lengthscale = property(lambda self: np.exp(-self.theta[1:]))      # tinygp Linear scale = exp(-log_scale)
+    trusted = property(lambda self: self.maximum_variance < self.variance_tol)
+
+    # -- train / attach ------------------------------------------------------------------------
+    def train(self, reason=0, optimise=None):
+        """gp.py:290-335.  optimise=False keeps theta (used by benchmarks with fixed hyper-parameters)."""
+        self.last_fit_train_size = self.database.size
+        print('#' + 17 * '-' + f"GP TRAINING ({self.name.upper()})" + 17 * '-')
+        print('# Timestep     :', self._step)
+        print('# Reason       :', ['DB', 'AL'][reason])
+        print('# Database size:', self.database.size)
+        optimise = self.optimise if optimise is None else optimise
+        X, Y, sigma = self.Xtrain, self.Ytrain, self.Yerr
+        theta0 = np.concatenate([[0.0], np.log(np.std(X, axis=0))])         # stress.py:281-284, 592-595
+        if optimise or self.theta is None:
+            if optimise:
+                res = minimize(neg_log_likelihood, theta0, args=(X, Y, sigma), jac=True, method='BFGS')
+                self.theta, obj = res.x, res.fun
+            else:
+                self.theta, obj = theta0, neg_log_likelihood(theta0, X, Y, sigma)[0]
+            print(f'# Objective    : {obj:.5g}')
+        self.attach()
+        if self._step > 0:
+            self.write()
+        if reason == 0:
+            print('#' + 50 * '-')
+
+    def attach(self):
+        """Factorise K on the device with the current data and hyper-parameters (gp.py:323)."""
+        X, Y = _lib.f64c(self.Xtrain), _lib.f64c(self.Ytrain)
+        dims = (C.c_int32 * len(self.active_dims))(*self.active_dims)
+        xs = _lib.f64c(self.database.X_scale[self.active_dims])
+        inv_scale = _lib.f64c(np.exp(-self.theta[1:]))
+        p = self._p
+        _lib.check(p._lib.gpf_gp_set_model(p._h, self.which, X.shape[0], X.shape[1], Y.shape[1], dims, _lib.as_dp(xs),
+                                           _lib.as_dp(X), _lib.as_dp(Y), float(np.exp(self.theta[0])),
+                                           _lib.as_dp(inv_scale), float(self.Yerr), float(self.Yscale)))
+        p._closures_stale = True
+        self._var_valid = False
+
+    def write(self):
+        h = self.history
+        h['step'].append(self._step)
+        h['database_size'].append(self.database.size)
+        h['variance'].append(self.kernel_variance)
+        h['obs_stddev'].append(self.obs_stddev)
+        h['maximum_variance'].append(self.maximum_variance)
+        h['variance_tol'].append(self.variance_tol)
+        for i, li in enumerate(self.active_dims):
+            h[f'lengthscale_{li}'].append(self.kernel_lengthscale[i])
+
+    # -- inference ---------------------------------------------------------------------------
+    def compute_variance(self, on_open_step):
+        """gp.py:406-410: variance field on the device, its maximum and the tolerance."""
+        p = self._p
+        mv = C.c_double(0)
+        tic = datetime.now()
+        _lib.check(p._lib.gpf_gp_variance(p._h, self.which, int(on_open_step), C.byref(mv)))
+        self.cumtime_infer += datetime.now() - tic
+        self.maximum_variance = mv.value
+        self.variance_tol = max(self.atol * self.Yerr * self.Yscale, self.rtol * self.Yscale)**2
+        self._var_valid = True
+
+    @property
+    def variance(self):
+        field = {0: _lib.FIELD_PRESSURE_VAR, 1: _lib.FIELD_WALL_XZ_VAR, 2: _lib.FIELD_WALL_YZ_VAR}[self.which]
+        return self._p._download(field, 1)[0]
+
+    def _infer_mean_var(self):
+        """Mean and variance of the current state (tests/test_inference.py:88-109 calls this directly)."""
+        p = self._p
+        p._sync_to_device()
+        p._closures_stale = True
+        self.compute_variance(on_open_step=False)
+        if self.which == 0:
+            mean = p._derived(_lib.FIELD_PRESSURE)[0]
+        else:
+            oi = 4 if self.which == 1 else 3
+            mean = np.stack([p._derived(_lib.FIELD_WALL_LOWER)[oi], p._derived(_lib.FIELD_WALL_UPPER)[oi]])
+        return mean, self.variance
+
+    def stage(self, predictor, compute_var, features_of_cell):
+        """The host side of predict() for one stage of an open step (gp.py:435-506).
+        Returns True if the device model changed (the caller re-evaluates the stage's closures)."""
+        changed = False
+        if predictor:
+            self._step += 1
+            self._pause = max(-1, self._pause - 1)
+            if self.last_fit_train_size < self.database.size:
+                tic = datetime.now()
+                self.train(reason=0)
+                self.cumtime_train += datetime.now() - tic
+                changed = True
+        compute_var = self.use_active_learning or compute_var            # stress.py:353-354, 617-618
+        if compute_var and predictor:
+            self.compute_variance(on_open_step=True)
+        if self.use_active_learning and predictor and self._pause < 0:
+            counter = 0
+            before = self.maximum_variance / self.variance_tol
+            while not self.trusted and counter < self.max_steps:
+                counter += 1
+                imax = int(np.argmax(self.variance))                      # gp.py:428-430
+                self.database.add_data(features_of_cell(imax)[None, :])
+                tic = datetime.now()
+                self.train(reason=1)
+                self.cumtime_train += datetime.now() - tic
+                changed = True
+                self.compute_variance(on_open_step=True)
+                after = self.maximum_variance / self.variance_tol
+                print(f"# AL {counter:2d}/{self.max_steps:2d}     : {before:.3f} --> {after:.3f}")
+                print('#' + 50 * '-')
+            if counter == self.max_steps:
+                print("# Active learning loop missed uncertainty threshold")
+                print(f"# Pause for {self.pause_steps} steps...")
+                print('#' + 50 * '-')
+                self._pause = self.pause_steps
+        return changed
+
+
+def attach_surrogates(problem, gp, database):
+    """Problem._select_gp_config (problem.py:643-660): press + shear-x in 1-D, + shear-y in 2-D."""
+    models = {}
+    if gp.get('press') is not None:
+        models['zz'] = Surrogate(problem, 'zz', gp['press'], database)
+    if gp.get('shear') is not None:
+        models['xz'] = Surrogate(problem, 'xz', gp['shear'], database)
+        if problem.grid['dim'] == 2:
+            models['yz'] = Surrogate(problem, 'yz', gp['shear'], database)
+    return models

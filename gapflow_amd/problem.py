@@ -38,8 +38,8 @@ class Problem:
     """Gap-averaged lubrication problem advanced by the fused MacCormack HIP kernel."""
 
     def __init__(self, options, grid, numerics, prop, geo, gp=None, database=None, extra_field=None, device=0):
-        if gp is not None or database is not None:
-            from .gp import attach_surrogates        # noqa: F401  (raises if unavailable)
+        if gp is not None and database is None:
+            raise IOError("GP closures need a training database (`db` section)")
         if database is not None and not getattr(database, 'has_mock_md', True):
             prop['shear'] = 0.                       # problem.py:110-113
             prop['bulk'] = 0.
@@ -75,10 +75,15 @@ class Problem:
         self._upload_topo()
 
         self._closures_stale = True
-        self.pressure = Pressure(self)
+        self.database = database
+        self._gp_models = {}
+        if gp is not None:
+            from .gp import attach_surrogates
+            self._gp_models = attach_surrogates(self, gp, database)
+        self.pressure = Pressure(self, self._gp_models.get('zz'))
         self.bulk_stress = BulkStress(self)
-        self.wall_stress_xz = WallStress(self, 'x')
-        self.wall_stress_yz = WallStress(self, 'y')
+        self.wall_stress_xz = WallStress(self, 'x', self._gp_models.get('xz'))
+        self.wall_stress_yz = WallStress(self, 'y', self._gp_models.get('yz'))
 
         sc = self._scalars()
         self._kinetic_energy_old = sc.ekin         # problem.py:670
@@ -297,8 +302,17 @@ class Problem:
     # -------------------------------------------------------------------------------------
     # run loop (problem.py:368-503)
     # -------------------------------------------------------------------------------------
+    def _features(self):
+        """(ncell, 7) GP feature matrix of the current state, all cells incl. ghosts (gp.py:223-232)."""
+        return np.vstack([self.q, self.topo.full[:3], self._extra]).reshape(7, -1).T
+
     def _pre_run(self):
         self._sync_to_device()
+        if self._gp_models:
+            # init_database + init of every surrogate (problem.py:418-424, stress.py:278-287, 586-598)
+            self.database.initialize(self._features(), self.grid['dim'])
+            for m in self._gp_models.values():
+                m.train(reason=0)
         _lib.check(self._lib.gpf_pre_run(self._h))
         if self._kinetic_energy_old is not None:
             _lib.check(self._lib.gpf_set_ekin_old(self._h, float(self._kinetic_energy_old)))
@@ -343,7 +357,43 @@ class Problem:
         """One MacCormack predictor-corrector time step (problem.py:509-569), on the device."""
         if self.step is None:
             raise RuntimeError("call _pre_run() (or run()) before update()")
-        self._advance(1, honor_stop=False)
+        if self._gp_models:
+            self._update_with_surrogates()
+        else:
+            self._advance(1, honor_stop=False)
+
+    def _update_with_surrogates(self):
+        """The same step through the stage-wise pipeline: the host sits between the stages because a
+        surrogate may retrain or extend its database there (gp.py:435-506, problem.py:532-560)."""
+        self._sync_to_device()
+        lib, h = self._lib, self._h
+        one_step_before_output = (self.step + 1) % self.options['write_freq'] == 0       # problem.py:530
+        feats = None
+
+        def features_of_cell(i):
+            nonlocal feats
+            if feats is None:
+                feats = self._features()        # active learning runs in the predictor only: working field == q
+            return feats[i]
+
+        _lib.check(lib.gpf_open_step(h))
+        for i in range(2):
+            _lib.check(lib.gpf_stage_closures(h))
+            changed = False
+            for name in ('zz', 'xz', 'yz'):
+                m = self._gp_models.get(name)
+                if m is not None:
+                    changed |= m.stage(i == 0, one_step_before_output, features_of_cell)
+            if changed:
+                _lib.check(lib.gpf_stage_closures(h))
+            _lib.check(lib.gpf_stage_advance(h, i))
+        sc = _lib.GpfScalars()
+        _lib.check(lib.gpf_close_step(h, C.byref(sc)))
+        if sc.invalid:
+            self._finalize(sc.invalid)
+            return
+        self._absorb([sc])
+        self._mark_device_advanced()
 
     def _finalize(self, reason):
         # problem.py:588-610: the device kept the pre-step field; closures refresh lazily
@@ -372,6 +422,10 @@ class Problem:
         self._tic = datetime.now()
         wf = self.options['write_freq']
         try:
+            while self._gp_models and not self.converged and self.step < self.max_it and not self._stop:
+                self.update()                   # surrogates: one host-driven step at a time
+                if self.step % wf == 0 and not silent and not self._stop:
+                    self.write()
             while not self.converged and self.step < self.max_it and not self._stop:
                 # steps until the next frame (problem.py:404) or max_it, whichever comes first; the
                 # device stops by itself at convergence, so a batch never overshoots the reference's loop
@@ -413,6 +467,9 @@ class Problem:
             self.history["vsound"].append(sc.v_sound)
         if fields and not self.options['silent']:
             self._writer.append_frame()
+        if params:
+            for m in self._gp_models.values():
+                m.write()
 
 
 def _in_main_thread():

@@ -14,10 +14,21 @@ class _Model:
     is_gp_model = False
     use_active_learning = False
 
-    def __init__(self, problem):
+    def __init__(self, problem, surrogate=None):
         self._problem = problem
+        self._surrogate = surrogate
         self.geo = problem.geo
         self.prop = problem.prop
+        if surrogate is not None:
+            self.is_gp_model = True
+            self.use_active_learning = surrogate.use_active_learning
+
+    def __getattr__(self, name):
+        # GP members (variance, _infer_mean_var, history, kernel_lengthscale, ...) live on the surrogate
+        s = self.__dict__.get('_surrogate')
+        if s is not None and not name.startswith('__'):
+            return getattr(s, name)
+        raise AttributeError(name)
 
 
 class Pressure(_Model):
@@ -51,8 +62,8 @@ class WallStress(_Model):
     of both objects is the full tensor (stress.py:346-362, problem.py:554-555).
     """
 
-    def __init__(self, problem, direction='x'):
-        super().__init__(problem)
+    def __init__(self, problem, direction='x', surrogate=None):
+        super().__init__(problem, surrogate)
         self.name = f'{direction}z'
         self._out_index = {'x': 4, 'y': 3}[direction]
 

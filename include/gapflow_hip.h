@@ -58,7 +58,10 @@ enum {
     GPF_FIELD_PRESSURE = 3,   /* 1 comp : derived, stress.py:600-622                            */
     GPF_FIELD_TAU_AVG = 4,    /* 3 comps: xx, yy, xy, stress.py:427-459                         */
     GPF_FIELD_WALL_LOWER = 5, /* 6 comps Voigt = wall_stress_xz.lower + wall_stress_yz.lower    */
-    GPF_FIELD_WALL_UPPER = 6  /* 6 comps Voigt (problem.py:554-555)                             */
+    GPF_FIELD_WALL_UPPER = 6, /* 6 comps Voigt (problem.py:554-555)                             */
+    GPF_FIELD_PRESSURE_VAR = 7,   /* GP predictive variances (stress.py:97, 499), 1 comp each         */
+    GPF_FIELD_WALL_XZ_VAR = 8,
+    GPF_FIELD_WALL_YZ_VAR = 9
 };
 
 /*
@@ -174,6 +177,39 @@ int gpf_predictor_corrector(int nx, int ny, const double* q, const double* p, co
 /* source(q,h,stress,stress_lower,stress_upper) -> out        (integrate.py:80-130); h = first 3 comps of the topography */
 int gpf_source(int nx, int ny, const double* q, const double* h, const double* stress,
                const double* lower, const double* upper, double* out);
+
+/* ---- the unfused step in pieces ------------------------------------------------------------- */
+/* For closures that need the host between stages (GP surrogates with active learning, gp.py:435-506):
+ * gpf_open_step copies q0; per stage gpf_stage_closures evaluates Pressure/WallStress/BulkStress on the
+ * working field (fixed-form laws, then the mean of every GP model that is set), gpf_stage_advance applies
+ * flux + source + ghost rules (problem.py:543-560); gpf_close_step averages, checks validity, updates
+ * dt / residual (problem.py:563-586).  gpf_step_unfused is exactly open, 2 x (closures, advance), close. */
+int gpf_open_step(gpf_handle* h);
+int gpf_stage_closures(gpf_handle* h);
+int gpf_stage_advance(gpf_handle* h, int stage);
+int gpf_close_step(gpf_handle* h, gpf_scalars_t* out);
+
+/* ---- GP surrogate closure: GaPFlow/models/gp.py, models/stress.py ------------------------------ */
+/* Stateless fit: K = A (1 + sqrt3 r) exp(-sqrt3 r) + sigma^2 I with r = ||inv_scale o (x - x')||
+ * (gp.py:598-603; tinygp GaussianProcess(kernel, X, diag=yerr^2)), Cholesky K = L L^T and alpha = K^-1 Y
+ * on the device: the library's own one-workgroup potrf/potrs kernels by default, rocSOLVER dpotrf/dpotrs
+ * when GPF_USE_ROCSOLVER=1 (its 930 MB shared object takes ~100 s to map on a cold node).  Xn [n][d] and Yn [n][m] row-major, already normalised.  Outputs (host,
+ * each may be NULL): L [n][n] row-major lower factor, alpha [n][m], logdet = log det K. */
+int gpf_gp_fit(int device, int n, int d, int m, const double* Xn, const double* Yn, double amp,
+               const double* inv_scale, double sigma, double* L, double* alpha, double* logdet);
+/* Attach / replace a surrogate of this problem: which = 0 pressure (m = 1; writes the pressure field),
+ * 1 wall shear xz, 2 wall shear yz (m = 2: lower, upper wall; Voigt index 4 / 3, stress.py:91, 356-357).
+ * dims[d]: feature index of each active dimension in [rho, jx, jy, h, dh/dx, dh/dy, extra]
+ * (gp.py:223-232); x_scale[d]: the database normalisers of those features (db.py:264-266);
+ * yscale: output scale (stress.py:230-242, 562-564).  The model is factorised on the device. */
+int gpf_gp_set_model(gpf_handle* h, int which, int n, int d, int m, const int32_t* dims, const double* x_scale,
+                     const double* Xn, const double* Yn, double amp, const double* inv_scale, double sigma,
+                     double yscale);
+int gpf_gp_clear_model(gpf_handle* h, int which);
+/* Predictive variance A - ||L^-1 k(X, x*)||^2 (gp.py:509-522) of model `which` at every cell, written to
+ * the GPF_FIELD_*_VAR field (times yscale^2); *max_var = its maximum (the active-learning criterion,
+ * gp.py:408).  on_open_step != 0: evaluate on the working field of an open step. */
+int gpf_gp_variance(gpf_handle* h, int which, int on_open_step, double* max_var);
 
 #ifdef __cplusplus
 }
