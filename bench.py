@@ -70,6 +70,21 @@ properties:
 """
 
 
+def measured_traffic():
+    """HBM bytes per k_step launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
+    this process): 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 note of MI355X_MICROARCH.md.  None if absent or
+    if it was taken on another grid size."""
+    best = None
+    pdir = os.path.join(ROOT, 'profiles')
+    if N_GRID != 4096 or not os.path.isdir(pdir):
+        return None, None
+    for d in sorted(os.listdir(pdir)):
+        f = os.path.join(pdir, d, 'traffic.json')
+        if os.path.exists(f):
+            best = (json.load(open(f))['hbm_bytes_per_launch'], f'profiles/{d}/traffic.json')
+    return best if best else (None, None)
+
+
 def cpu_baseline(sample_n=1024, steps=4):
     """The oracle on a bounded sample: same YAML with Nx=Ny=sample_n, `steps` timed steps after one warm-up."""
     from oracle.problem import OracleProblem
@@ -116,6 +131,7 @@ def run_single(args):
     cells = N_GRID * N_GRID
     kernel_s = kt.value / nk / 1e3
     achieved = BYTES_PER_CELL * cells / kernel_s / 1e9
+    traffic, traffic_src = measured_traffic()
     out = {
         "metric": "Mcell-updates/s (fp64), 4096^2 grid", "value": cells * args.steps / wall / 1e6,
         "unit": "Mcell-updates/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -124,7 +140,8 @@ def run_single(args):
         "config": {"workload": f"2D journal bearing {N_GRID}x{N_GRID}, fixed DH EOS, all-periodic, adaptive CFL 0.5 "
                                "(BASELINE.json configs[2])", "slabs": 1},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_step<DH>",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "k_step<DH>",
                      "kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_launch": BYTES_PER_CELL * cells,
                      "all_kernels_ms_per_step": tt.value / nk},
     }
