@@ -1,0 +1,84 @@
+"""Rows next to the hot path: piezo-viscosity closures and the output files the reference's tools read."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PIEZO = """
+options: {{silent: True}}
+grid: {{Nx: 64, Ny: {ny}, Lx: 0.05, Ly: {ly}, xE: ['D', 'N', 'N'], xW: ['D', 'N', 'N'], xE_D: {rho0}, xW_D: {rho0}}}
+geometry: {{type: parabolic, hmin: 1.e-5, hmax: 4.e-5, U: 10., V: {v}}}
+numerics: {{CFL: 0.4, adaptive: 1, max_it: 100}}
+properties:
+    EOS: {eos}
+    shear: 0.05
+    bulk: 0.01
+    rho0: {rho0}
+    piezo: {{name: {name}}}
+"""
+
+
+@pytest.mark.parametrize('eos,name,rho0,ny', [('DH', 'Barus', 877.7007, 1), ('DH', 'Roelands', 877.7007, 12),
+                                                ('Bayada', 'Dukler', 850., 1), ('Bayada', 'McAdams', 850., 12)])
+def test_piezoviscosity_steps_match_oracle(hiplib, eos, name, rho0, ny):
+    """models/viscosity.py:34-66 inside the stress closures (stress.py:306-312): 20 steps against the oracle."""
+    from gapflow_amd import Problem
+    from oracle.problem import OracleProblem
+    text = PIEZO.format(eos=eos, name=name, rho0=rho0, ny=ny, ly=0.01 if ny > 1 else 1., v=1. if ny > 1 else 0.)
+    gpu, cpu = Problem.from_string(text), OracleProblem.from_string(text)
+    gpu._pre_run()
+    cpu._pre_run()
+    for _ in range(20):
+        gpu.update()
+        cpu.update()
+    for c in range(3):
+        scale = np.abs(cpu.q[c]).max() or 1.
+        assert np.abs(gpu.q[c] - cpu.q[c]).max() <= 1e-9 * scale
+    np.testing.assert_allclose(gpu.dt, cpu.dt, rtol=1e-10)
+    cpu.update_closures()
+    np.testing.assert_allclose(gpu.bulk_stress.stress, cpu.tau_avg, rtol=1e-9, atol=1e-12 * np.abs(cpu.tau_avg).max())
+
+
+def test_shear_thinning_is_refused_not_approximated(hiplib):
+    from gapflow_amd import Problem
+    with pytest.raises(NotImplementedError):
+        Problem.from_string(PIEZO.format(eos='DH', name='Barus', rho0=877.7007, ny=1, ly=1., v=0.)
+                            + "    thinning: {name: Eyring}\n")
+
+
+def test_output_files_have_the_reference_layout(hiplib, tmp_path):
+    """sol.nc / topo.nc / history.csv / config.yml as the reference's viz tools read them
+    (viz/animations.py:173-182, viz/plotting.py:331-348; problem.py:385-391)."""
+    from scipy.io import netcdf_file
+    import yaml
+    from gapflow_amd import Problem
+    sim = f"""
+options: {{output: {tmp_path}/run, write_freq: 10, use_tstamp: False, silent: False}}
+grid: {{Nx: 50, Ny: 1, dx: 1.e-5, dy: 1., xE: ['D', 'N', 'N'], xW: ['D', 'N', 'N'], xE_D: 877.7007, xW_D: 877.7007}}
+geometry: {{type: journal, CR: 1.e-2, eps: 0.7, U: 0.1, V: 0.}}
+numerics: {{tol: 1e-9, dt: 1e-10, max_it: 35}}
+properties: {{shear: 0.0794, bulk: 0., EOS: DH, rho0: 877.7007}}
+"""
+    prob = Problem.from_string(sim)
+    prob.run()
+    out = os.path.join(tmp_path, 'run')
+    assert sorted(os.listdir(out)) == ['config.yml', 'history.csv', 'sol.nc', 'topo.nc']
+    rows = open(os.path.join(out, 'history.csv')).read().strip().split('\n')
+    assert rows[0] == 'step,time,ekin,residual,vsound'
+    assert [int(float(r.split(',')[0])) for r in rows[1:]] == [0, 10, 20, 30, 35]      # frames at write_freq + the final one
+    with netcdf_file(os.path.join(out, 'sol.nc'), 'r', mmap=False) as f:
+        assert f.variables['solution'].shape == (5, 3, 1, 52, 3)
+        assert f.variables['pressure'].shape == (5, 52, 3)
+        assert f.variables['wall_stress_xz'].shape == (5, 12, 1, 52, 3)
+        assert f.variables['wall_stress_yz'].shape == (5, 12, 1, 52, 3)
+        np.testing.assert_array_equal(f.variables['solution'][-1][:, 0], prob.q)
+        # halves of the shared components + own shear component (stress.py:346-362)
+        np.testing.assert_allclose(f.variables['wall_stress_xz'][-1][4, 0], prob.wall_stress_xz.lower[4])
+    with netcdf_file(os.path.join(out, 'topo.nc'), 'r', mmap=False) as f:
+        assert f.variables['topography'].shape == (1, 4, 1, 52, 3)
+        np.testing.assert_array_equal(f.variables['topography'][0][:, 0], prob.topo.full)
+    cfg = yaml.safe_load(open(os.path.join(out, 'config.yml')))
+    assert cfg['grid']['Nx'] == 50 and cfg['prop']['EOS'] == 'DH'
