@@ -61,9 +61,9 @@ SIGNATURES = {
     'gpf_scalars': (C.c_int, [C.c_void_p, C.POINTER(GpfScalars)]),
     'gpf_set_ekin_old': (C.c_int, [C.c_void_p, C.c_double]),
     'gpf_set_dt': (C.c_int, [C.c_void_p, C.c_double]),
-    'gpf_halo_buffers': (C.c_int, [C.c_void_p, _VPP, _VPP, _VPP, _VPP, C.POINTER(C.c_size_t)]),
-    'gpf_step_local': (C.c_int, [C.c_void_p, C.c_int, _VPP]),
-    'gpf_step_commit': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    'gpf_slab_message': (C.c_int, [C.c_void_p, _VPP, C.POINTER(C.c_size_t)]),
+    'gpf_step_local': (C.c_int, [C.c_void_p, C.c_int]),
+    'gpf_step_commit': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     'gpf_state': (C.c_int, [C.c_void_p, C.POINTER(GpfScalars)]),
     'gpf_set_seam_topo': (C.c_int, [C.c_void_p, C.c_int, _DP, C.c_size_t]),
     'gpf_predictor_corrector': (C.c_int, [C.c_int, C.c_int, _DP, _DP, _DP, C.c_int, _DP, _DP]),

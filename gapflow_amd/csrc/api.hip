@@ -52,7 +52,7 @@ struct gpf_handle {
     double* g1 = nullptr;                   // g1x [3][pitch] followed by g1y [3][Nx+2]
     double* seam = nullptr;                 // [2 edges][2 rows][4: h,hx,hy,Ls][pitch]
     bool has_seam[2] = {false, false};
-    double* halo = nullptr;                 // send_lo, send_hi, recv_lo, recv_hi: each [3][pitch]; then the 8-double slab record
+    double* halo = nullptr;                 // this slab's all-gather message: first row, last row (3 x pitch each), 8-double record
     StepState* st = nullptr;
     Partial* partials = nullptr;
     int npartials = 0, nstrips = 0, nchunks = 0, rows_per_chunk = 0, nghost_blocks = 0;
@@ -754,54 +754,55 @@ extern "C" int gpf_source(int nx, int ny, const double* q, const double* hh, con
 // ---------------------------------------------------------------------------------------------
 // slab decomposition
 // ---------------------------------------------------------------------------------------------
+static size_t halo_len(gpf_handle* h) { return (size_t)6 * h->L.pitch + 8; }
+
 static int ensure_halo(gpf_handle* h) {
     if (h->halo) return GPF_OK;
-    const size_t n = (size_t)12 * h->L.pitch + 8;
-    HIP_TRY(hipMalloc(&h->halo, n * sizeof(double)));
-    HIP_TRY(hipMemsetAsync(h->halo, 0, n * sizeof(double), h->stream));
+    HIP_TRY(hipMalloc(&h->halo, halo_len(h) * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(h->halo, 0, halo_len(h) * sizeof(double), h->stream));
     return GPF_OK;
 }
 
-extern "C" int gpf_halo_buffers(gpf_handle* h, void** send_lo, void** send_hi, void** recv_lo, void** recv_hi,
-                                size_t* count) {
-    if (!h || !send_lo || !send_hi || !recv_lo || !recv_hi || !count) return fail(GPF_ERR_INVALID, "gpf_halo_buffers: null argument");
+extern "C" int gpf_slab_message(gpf_handle* h, void** message, size_t* count) {
+    if (!h || !message || !count) return fail(GPF_ERR_INVALID, "gpf_slab_message: null argument");
     HIP_TRY(hipSetDevice(h->cfg.device));
     GPF_TRY(ensure_halo(h));
-    const size_t m = (size_t)3 * h->L.pitch;
-    *send_lo = h->halo; *send_hi = h->halo + m; *recv_lo = h->halo + 2 * m; *recv_hi = h->halo + 3 * m;
-    *count = m;
+    *message = h->halo;
+    *count = halo_len(h);
     return GPF_OK;
 }
 
-static HaloArgs halo_args(gpf_handle* h, int honor_stop) {
-    const size_t m = (size_t)3 * h->L.pitch;
+static HaloArgs halo_args(gpf_handle* h, int honor_stop, const double* gathered, int rank_lo, int rank_hi) {
     HaloArgs a;
     a.qa = h->q[0]; a.qb = h->q[1];
-    a.send_lo = h->halo; a.send_hi = h->halo + m; a.recv_lo = h->halo + 2 * m; a.recv_hi = h->halo + 3 * m;
+    a.msg = h->halo; a.gathered = gathered; a.rank_lo = rank_lo; a.rank_hi = rank_hi;
     a.st = h->st; a.L = h->L; a.E = h->E; a.honor_stop = honor_stop;
     return a;
 }
 
-extern "C" int gpf_step_local(gpf_handle* h, int honor_stop, void** totals) {
-    if (!h || !totals) return fail(GPF_ERR_INVALID, "gpf_step_local: null argument");
+extern "C" int gpf_step_local(gpf_handle* h, int honor_stop) {
+    if (!h) return fail(GPF_ERR_INVALID, "gpf_step_local: null handle");
     if (!h->pre_run_done) return fail(GPF_ERR_STATE, "gpf_step_local: call gpf_pre_run first");
     HIP_TRY(hipSetDevice(h->cfg.device));
     GPF_TRY(ensure_halo(h));
-    double* rec = h->halo + (size_t)12 * h->L.pitch;
+    double* rec = h->halo + (size_t)6 * h->L.pitch;
     GPF_TRY(enqueue_step(h, honor_stop, h->host_step, rec));
-    hipLaunchKernelGGL(k_halo_pack, dim3((h->L.pitch + 255) / 256), dim3(256), 0, h->stream, halo_args(h, honor_stop));
+    hipLaunchKernelGGL(k_halo_pack, dim3((h->L.pitch + 255) / 256), dim3(256), 0, h->stream,
+                       halo_args(h, honor_stop, nullptr, -1, -1));
     HIP_TRY(hipGetLastError());
-    *totals = rec;
     return GPF_OK;
 }
 
-extern "C" int gpf_step_commit(gpf_handle* h, int honor_stop, const void* gathered, int nranks) {
+extern "C" int gpf_step_commit(gpf_handle* h, int honor_stop, const void* gathered, int nranks, int rank_lo, int rank_hi) {
     if (!h || !gathered || nranks < 1) return fail(GPF_ERR_INVALID, "gpf_step_commit: bad argument");
+    if (rank_lo >= nranks || rank_hi >= nranks) return fail(GPF_ERR_INVALID, "gpf_step_commit: neighbour rank out of range");
     if (!h->halo) return fail(GPF_ERR_STATE, "gpf_step_commit without gpf_step_local");
     HIP_TRY(hipSetDevice(h->cfg.device));
-    hipLaunchKernelGGL(k_halo_unpack, dim3((h->L.pitch + 255) / 256), dim3(256), 0, h->stream, halo_args(h, honor_stop));
-    hipLaunchKernelGGL(k_commit_gathered, dim3(1), dim3(1), 0, h->stream, h->st, (const double*)gathered, nranks,
-                       h->log, (long long)h->host_step, (long long)h->log_cap, honor_stop);
+    hipLaunchKernelGGL(k_halo_unpack, dim3((h->L.pitch + 255) / 256), dim3(256), 0, h->stream,
+                       halo_args(h, honor_stop, (const double*)gathered, rank_lo, rank_hi));
+    hipLaunchKernelGGL(k_commit_gathered, dim3(1), dim3(1), 0, h->stream, h->st, (const double*)gathered,
+                       (long long)halo_len(h), (long long)6 * h->L.pitch, nranks, h->log, (long long)h->host_step,
+                       (long long)h->log_cap, honor_stop);
     HIP_TRY(hipGetLastError());
     return GPF_OK;
 }

@@ -287,10 +287,15 @@ __global__ __launch_bounds__(256) void k_finish(const FinishArgs a) {
     }
 }
 
-// slab mode: halo messages <-> rows of the field the step has just produced (buffer !parity)
+// slab mode.  Every rank contributes ONE message per step to a single all-gather:
+//     [ first interior row (3 x pitch) | last interior row (3 x pitch) | 8-double record ]
+// taken from the field the step has just produced (buffer !parity); after the all-gather each rank scatters
+// its neighbours' rows into its outer rows and reduces all records in rank order.
 struct HaloArgs {
     double* qa; double* qb;
-    double* send_lo; double* send_hi; double* recv_lo; double* recv_hi;    // each [3][pitch]
+    double* msg;                // this rank's message, 6*pitch + 8 doubles
+    const double* gathered;     // nranks messages (commit side)
+    int rank_lo, rank_hi;       // rank whose LAST row fills my row 0 / whose FIRST row fills my row Nx+1; -1: none
     const StepState* st;
     Layout L; Edges E;
     int honor_stop;
@@ -301,8 +306,8 @@ __global__ void k_halo_pack(const HaloArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.L.pitch) return;
     for (int c = 0; c < 3; ++c) {
-        a.send_lo[c * a.L.pitch + i] = q[c * a.L.plane + (long long)1 * a.L.pitch + i];
-        a.send_hi[c * a.L.pitch + i] = q[c * a.L.plane + (long long)a.L.Nx * a.L.pitch + i];
+        a.msg[c * a.L.pitch + i] = q[c * a.L.plane + (long long)1 * a.L.pitch + i];
+        a.msg[(3 + c) * a.L.pitch + i] = q[c * a.L.plane + (long long)a.L.Nx * a.L.pitch + i];
     }
 }
 __global__ void k_halo_unpack(const HaloArgs a) {
@@ -310,20 +315,22 @@ __global__ void k_halo_unpack(const HaloArgs a) {
     double* q = a.st->parity ? a.qa : a.qb;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.L.pitch) return;
+    const long long len = 6ll * a.L.pitch + 8;
     for (int c = 0; c < 3; ++c) {
-        if (a.E.halo[0]) q[c * a.L.plane + i] = a.recv_lo[c * a.L.pitch + i];
-        if (a.E.halo[1]) q[c * a.L.plane + (long long)(a.L.Nx + 1) * a.L.pitch + i] = a.recv_hi[c * a.L.pitch + i];
+        if (a.E.halo[0] && a.rank_lo >= 0) q[c * a.L.plane + i] = a.gathered[a.rank_lo * len + (3 + c) * a.L.pitch + i];
+        if (a.E.halo[1] && a.rank_hi >= 0)
+            q[c * a.L.plane + (long long)(a.L.Nx + 1) * a.L.pitch + i] = a.gathered[a.rank_hi * len + c * a.L.pitch + i];
     }
 }
 
 // slab mode: reduce the gathered per-slab records in rank order (identical on every rank), then commit
-__global__ void k_commit_gathered(StepState* st, const double* rec, int nranks, LogEntry* log, long long log_base,
-                                  long long log_cap, int honor_stop) {
+__global__ void k_commit_gathered(StepState* st, const double* gathered, long long len, long long rec_off, int nranks,
+                                  LogEntry* log, long long log_base, long long log_cap, int honor_stop) {
     if (st->invalid != 0 || (honor_stop && (st->converged || st->step >= st->max_it))) return;
     double ekin = 0.0, v2 = 0.0, c2 = 0.0;
     int flags = 0;
     for (int r = 0; r < nranks; ++r) {
-        const double* p = rec + 8 * r;
+        const double* p = gathered + r * len + rec_off;
         ekin += p[0];
         v2 = fmax(v2, p[1]); c2 = fmax(c2, p[2]);
         flags |= (int)p[3];

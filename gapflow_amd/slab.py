@@ -3,13 +3,13 @@
 The reference is single-process (README.md:60-61); this module is new.  The grid is cut along x
 (the slow axis of the device planes, so halo rows are contiguous).  A fused step needs its
 neighbours' field only one row deep (the composed MacCormack stencil has radius 1, see
-csrc/step_kernel.hip), so per time step each rank exchanges ONE row with each neighbour and
-all-gathers one 64-byte record (sum Ekin, max v^2, max c^2, validity) -- both after the stencil
+csrc/step_kernel.hip), so per time step each rank needs ONE row from each neighbour plus everybody's 64-byte record
+(sum Ekin, max v^2, max c^2, validity).  Both travel in a single all-gather after the stencil
 kernel, before the dt/residual commit:
 
-    gpf_step_local   (prepass + fused stencil + local ghost rules + pack send rows + local record)
-    all_gather(record)  |  isend/irecv(halo rows)          <- torch.distributed (RCCL over xGMI)
-    gpf_step_commit  (scatter received rows, reduce records in rank order, advance dt/residual)
+    gpf_step_local   (prepass + fused stencil + local ghost rules + message: first row, last row, record)
+    all_gather_into_tensor(gathered, message)               <- torch.distributed (RCCL over xGMI)
+    gpf_step_commit  (scatter the neighbours' rows, reduce records in rank order, advance dt/residual)
 
 Everything is enqueued on one stream; there is no host synchronisation inside `advance`.
 Reductions are combined in rank order on every rank, so all ranks hold bit-identical dt.
@@ -17,12 +17,13 @@ Reductions are combined in rank order on every rank, so all ranks hold bit-ident
 Kinds of a slab's outer rows (gpf_config.halo_lo/hi): 0 physical ghost row (local rule),
 1 copy of the neighbour's interior row, 2 the domain's periodic ghost row (filled by the ring).
 
-`SlabDriver` is backend-neutral (any engine with step_local / halo_tensors / commit); the product
+`SlabDriver` is backend-neutral (any engine with message / step_local / commit); the product
 engine is `HipSlabEngine`.  tests/test_slab_gloo.py drives the same driver with a CPU engine over
 gloo to check partitioning, message pairing and the rank-ordered reduction.
 """
 import ctypes as C
 import io as _io
+import os
 from copy import deepcopy
 
 import numpy as np
@@ -78,40 +79,74 @@ class SlabLayout:
         return g
 
 
-def exchange_and_gather(layout, record, gathered, send_lo, send_hi, recv_lo, recv_hi, dist):
-    """One all-gather of the 8-double records and one paired halo exchange.
-
-    Message pairing relies on issue order (RCCL has no tags): every rank posts
-    send_hi -> upper, recv_lo <- lower, send_lo -> lower, recv_hi <- upper, so that with two ranks on a
-    periodic ring (lower == upper) the first receive still meets the peer's first send."""
-    dist.all_gather_into_tensor(gathered, record)
-    ops = []
-    if layout.upper is not None:
-        ops.append(dist.P2POp(dist.isend, send_hi, layout.upper))
-    if layout.lower is not None:
-        ops.append(dist.P2POp(dist.irecv, recv_lo, layout.lower))
-        ops.append(dist.P2POp(dist.isend, send_lo, layout.lower))
-    if layout.upper is not None:
-        ops.append(dist.P2POp(dist.irecv, recv_hi, layout.upper))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-
-
 class SlabDriver:
-    """Runs the split step of an engine: step_local -> (gather | exchange) -> commit."""
+    """Runs the split step of an engine: step_local -> ONE all-gather -> commit.
+
+    Every rank contributes one message [first row | last row | record]; after the all-gather each rank picks its
+    neighbours' rows out of the gathered buffer.  (Point-to-point sends would move 8x fewer bytes, but the rows are
+    ~100 KB and a step is latency-bound: one collective instead of an all-gather plus a send/recv group halves both
+    the host dispatch and the number of RCCL kernels per step.)"""
 
     def __init__(self, engine, layout, dist, torch):
         self.engine, self.layout, self.dist = engine, layout, dist
-        self.send_lo, self.send_hi, self.recv_lo, self.recv_hi = engine.halo_tensors()
-        self.gathered = torch.zeros(8 * layout.world, dtype=torch.float64, device=self.send_lo.device)
+        self.message = engine.message()
+        self.gathered = torch.zeros(self.message.numel() * layout.world, dtype=torch.float64, device=self.message.device)
+        # rank whose LAST row is my row 0 / whose FIRST row is my row Nx+1
+        self.rank_lo = -1 if layout.lower is None else layout.lower
+        self.rank_hi = -1 if layout.upper is None else layout.upper
+
+        self.torch = torch
+        self.enqueued = 0               # steps issued since pre_run (the predictor direction may alternate with it)
+        self.graph = None
+        self.graph_honor = None
+        self.use_graph = os.environ.get('GPF_SLAB_GRAPH', '0') == '1' and self.message.is_cuda
+
+    def _eager(self, n, honor_stop):
+        for _ in range(n):
+            self.engine.step_local(honor_stop)
+            self.dist.all_gather_into_tensor(self.gathered, self.message)
+            self.engine.commit(self.gathered, honor_stop, self.rank_lo, self.rank_hi)
+        self.enqueued += n
+
+    def _capture(self, honor_stop):
+        """Record two consecutive steps (an even and an odd one: MC_order 0 alternates the sweep direction,
+        problem.py:521-522) -- library kernels and the RCCL all-gather -- into one hipGraph."""
+        torch = self.torch
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.engine.set_stream(side.cuda_stream)
+            try:
+                with torch.cuda.graph(g, stream=side):
+                    for _ in range(2):
+                        self.engine.step_local(honor_stop)
+                        self.dist.all_gather_into_tensor(self.gathered, self.message)
+                        self.engine.commit(self.gathered, honor_stop, self.rank_lo, self.rank_hi)
+            finally:
+                self.engine.set_stream(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.current_stream().wait_stream(side)
+        self.engine.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.graph, self.graph_honor = g, honor_stop
 
     def advance(self, n, honor_stop=False):
-        for _ in range(n):
-            record = self.engine.step_local(honor_stop)
-            exchange_and_gather(self.layout, record, self.gathered, self.send_lo, self.send_hi,
-                                self.recv_lo, self.recv_hi, self.dist)
-            self.engine.commit(self.gathered, honor_stop)
+        """n time steps; with GPF_SLAB_GRAPH=1 pairs of steps are replayed from a captured hipGraph, which takes
+        the per-step host dispatch (two library calls and one collective) off the critical path."""
+        if not self.use_graph or n < 6:
+            return self._eager(n, honor_stop)
+        if self.enqueued == 0:
+            self._eager(2, honor_stop)          # first calls allocate and plan: keep them out of the capture
+            n -= 2
+        if self.enqueued % 2:
+            self._eager(1, honor_stop)
+            n -= 1
+        if self.graph is None or self.graph_honor != honor_stop:
+            self._capture(honor_stop)           # capturing does not execute
+        for _ in range(n // 2):
+            self.graph.replay()
+        self.enqueued += 2 * (n // 2)
+        self.engine.resync()                    # the library's own step counter did not see the replays
+        self._eager(n % 2, honor_stop)
 
 
 class _DeviceArray:
@@ -126,26 +161,26 @@ class HipSlabEngine:
 
     def __init__(self, lib, handle, torch, world):
         self.lib, self.h, self.torch, self.world = lib, handle, torch, world
-        p = [C.c_void_p() for _ in range(4)]
-        n = C.c_size_t(0)
-        _lib.check(lib.gpf_halo_buffers(handle, *[C.byref(x) for x in p], C.byref(n)))
-        self._bufs = [torch.as_tensor(_DeviceArray(x.value, n.value), device='cuda') for x in p]
-        self._rec_ptr = None
-        self._rec = None
+        p, n = C.c_void_p(), C.c_size_t(0)
+        _lib.check(lib.gpf_slab_message(handle, C.byref(p), C.byref(n)))
+        self._msg = torch.as_tensor(_DeviceArray(p.value, n.value), device='cuda')
 
-    def halo_tensors(self):
-        return self._bufs
+    def message(self):
+        return self._msg
 
     def step_local(self, honor_stop):
-        rec = C.c_void_p()
-        _lib.check(self.lib.gpf_step_local(self.h, int(honor_stop), C.byref(rec)))
-        if self._rec_ptr != rec.value:
-            self._rec_ptr = rec.value
-            self._rec = self.torch.as_tensor(_DeviceArray(rec.value, 8), device='cuda')
-        return self._rec
+        _lib.check(self.lib.gpf_step_local(self.h, int(honor_stop)))
 
-    def commit(self, gathered, honor_stop):
-        _lib.check(self.lib.gpf_step_commit(self.h, int(honor_stop), C.c_void_p(gathered.data_ptr()), self.world))
+    def commit(self, gathered, honor_stop, rank_lo, rank_hi):
+        _lib.check(self.lib.gpf_step_commit(self.h, int(honor_stop), C.c_void_p(gathered.data_ptr()), self.world,
+                                            int(rank_lo), int(rank_hi)))
+
+    def set_stream(self, stream_ptr):
+        _lib.check(self.lib.gpf_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def resync(self):
+        sc = _lib.GpfScalars()
+        _lib.check(self.lib.gpf_state(self.h, C.byref(sc)))     # synchronises; re-reads the device step counter
 
 
 class SlabProblem:

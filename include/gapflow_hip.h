@@ -147,21 +147,20 @@ int gpf_set_ekin_old(gpf_handle* h, double value);            /* kinetic_energy_
 int gpf_set_dt(gpf_handle* h, double dt);
 
 /* ---- slab decomposition (one process per GPU, x-slabs) ------------------------------------ */
-/* Device addresses of the four packed halo messages, each *count doubles long
- * (3 components x padded row): send_lo/send_hi carry the first/last interior row of the field
- * the current step has produced, recv_lo/recv_hi are scattered into rows ix=0 / ix=Nx+1 by
- * gpf_step_commit.  Fixed for the life of the handle (usable as RCCL / torch.distributed buffers). */
-int gpf_halo_buffers(gpf_handle* h, void** send_lo, void** send_hi, void** recv_lo, void** recv_hi,
-                     size_t* count);
-/* Split step.  gpf_step_local: ghost-stage prepass + fused stencil update + local ghost rules +
- * packing of the send rows; *totals = device address of this slab's 8-double record
- * [sum Ekin, max v^2, max c^2 (NaN encoded as +inf), invalid flags, 0...].  Between the two
- * calls the caller exchanges the halo messages and all-gathers the records of all slabs (rank
- * order) into `gathered` (device, 8*nranks doubles).  gpf_step_commit scatters the received rows,
- * reduces the records in rank order and advances dt / residual / step exactly as gpf_step does.
+/* One message per slab and step feeds a SINGLE all-gather: *message (device, *count = 6*pitch + 8 doubles) =
+ * [first interior row | last interior row | 8-double record] of the field the current step has produced, where a
+ * row is 3 components x the padded row and the record is [sum Ekin, max v^2, max c^2 (NaN as +inf), invalid flags,
+ * 0...].  The address is fixed for the life of the handle (usable as an RCCL / torch.distributed buffer).
+ *
+ * gpf_step_local : ghost-stage prepass + fused stencil + local ghost rules + the message.
+ * (caller)       : all-gather the messages of all slabs, rank order, into `gathered` (device, nranks * count).
+ * gpf_step_commit: scatter the neighbours' rows into rows ix=0 / ix=Nx+1 (rank_lo: the rank whose LAST row is my
+ *                  row 0, rank_hi: the rank whose FIRST row is my row Nx+1, -1 = physical edge), reduce the records
+ *                  in rank order and advance dt / residual / step exactly as gpf_step does.
  * Everything is enqueued on the handle's stream; neither call synchronises with the host. */
-int gpf_step_local(gpf_handle* h, int honor_stop, void** totals);
-int gpf_step_commit(gpf_handle* h, int honor_stop, const void* gathered, int nranks);
+int gpf_slab_message(gpf_handle* h, void** message, size_t* count);
+int gpf_step_local(gpf_handle* h, int honor_stop);
+int gpf_step_commit(gpf_handle* h, int honor_stop, const void* gathered, int nranks, int rank_lo, int rank_hi);
 /* Read back the run state after a batch of split steps (synchronises). */
 int gpf_state(gpf_handle* h, gpf_scalars_t* out);
 /* Topography across a periodic seam (halo kind 2): the rows the far side's first interior cell and

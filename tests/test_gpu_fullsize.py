@@ -59,9 +59,9 @@ def test_flip_symmetry_2048(hiplib):
         assert np.abs(x - y).max() <= 1e-9 * scale + 1e-7
 
 
-def test_slider_1024_batching_and_restart_invariance(hiplib):
-    """configs[1] (1024^2 inclined slider, D/N in x): 40 steps in one batch == 4 batches of 10 == a field downloaded
-    after 20 steps, uploaded into a fresh problem and continued (host<->device round trip is lossless)."""
+def test_slider_1024_batching_invariance_and_ghost_rules(hiplib):
+    """configs[1] (1024^2 inclined slider, D/N in x): 40 steps in one batch == 4 batches of 10, and the ghost cells of
+    the result obey the boundary rules."""
     text = """
 options: {silent: True}
 grid: {Nx: 1024, Ny: 1024, Lx: 0.1, Ly: 0.1, xE: ['D', 'N', 'N'], xW: ['D', 'N', 'N'], xE_D: 877.7007, xW_D: 877.7007}

@@ -18,7 +18,9 @@ properties: {EOS: DH, shear: 0.0794, bulk: 0., rho0: 877.7007}
 """
 
 
-def test_one_rank_group_equals_serial_problem(hiplib):
+@pytest.mark.parametrize('graph', ['0', '1'])
+def test_one_rank_group_equals_serial_problem(hiplib, graph, monkeypatch):
+    monkeypatch.setenv('GPF_SLAB_GRAPH', graph)      # '1': pairs of steps replayed from a captured hipGraph
     import torch
     import torch.distributed as dist
     from gapflow_amd import Problem
@@ -33,8 +35,10 @@ def test_one_rank_group_equals_serial_problem(hiplib):
     try:
         slab = SlabProblem.from_string(SIM)
         slab.pre_run()
-        slab.advance(20)
+        slab.advance(13)
+        slab.advance(7)
         st = slab.state()
+        assert (slab.driver.graph is not None) == (graph == '1')
         serial = Problem.from_string(SIM)
         serial._pre_run()
         serial._advance(20, honor_stop=False)
@@ -56,7 +60,6 @@ class StagedGloo:
     def __init__(self, dist, torch):
         self._d, self._t = dist, torch
         self.ReduceOp = dist.ReduceOp
-        self.isend, self.irecv = 'isend', 'irecv'
 
     def get_rank(self):
         return self._d.get_rank()
@@ -74,29 +77,6 @@ class StagedGloo:
         c = t.cpu()
         self._d.all_reduce(c, op=op)
         t.copy_(c)
-
-    def P2POp(self, kind, tensor, peer):
-        return (kind, tensor, peer)
-
-    def batch_isend_irecv(self, ops):
-        self._t.cuda.synchronize()
-        reqs, back = [], []
-        for kind, tensor, peer in ops:
-            if kind == 'isend':
-                reqs.append(self._d.isend(tensor.cpu(), peer))
-            else:
-                c = self._t.empty(tensor.shape, dtype=tensor.dtype)
-                reqs.append(self._d.irecv(c, peer))
-                back.append((tensor, c))
-
-        class _Done:
-            def wait(self_inner):
-                pass
-        for r in reqs:
-            r.wait()
-        for dst, c in back:
-            dst.copy_(c)
-        return [_Done()]
 
 
 def _slab_worker(rank, world, port, text, nsteps, out_dir):

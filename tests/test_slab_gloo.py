@@ -58,8 +58,8 @@ class OracleSlabEngine:
         p.topo = gtopo[:, layout.rows()].copy()
         self.kinds = (layout.kind_lo, layout.kind_hi)
         ny2 = d['grid']['Ny'] + 2
-        self.bufs = [torch.zeros(3 * ny2, dtype=torch.float64) for _ in range(4)]
-        self.rec = torch.zeros(8, dtype=torch.float64)
+        self.rowlen = 3 * ny2
+        self.msg = torch.zeros(2 * self.rowlen + 8, dtype=torch.float64)      # [first row | last row | record]
         full_bc = p.communicate_ghost_buffers
 
         def bc():   # y rules everywhere, x rules only on physical edges (halo rows belong to the exchange)
@@ -71,8 +71,8 @@ class OracleSlabEngine:
                 p.q[:, -1, :] = keep[1]
         p.communicate_ghost_buffers = bc
 
-    def halo_tensors(self):
-        return self.bufs
+    def message(self):
+        return self.msg
 
     def pre_run(self, dt, ekin_old):
         p = self.p
@@ -107,19 +107,20 @@ class OracleSlabEngine:
         p.q[...] = (p.q + self.q0) / 2.0
         p.communicate_ghost_buffers()
         e, v2, c2, fl = self.local_scalars()
-        self.rec[:] = self.torch.tensor([e, v2, c2, fl, 0, 0, 0, 0], dtype=self.torch.float64)
-        self.bufs[0][:] = self.torch.from_numpy(p.q[:, 1, :].reshape(-1).copy())
-        self.bufs[1][:] = self.torch.from_numpy(p.q[:, -2, :].reshape(-1).copy())
-        return self.rec
+        n = self.rowlen
+        self.msg[:n] = self.torch.from_numpy(p.q[:, 1, :].reshape(-1).copy())
+        self.msg[n:2 * n] = self.torch.from_numpy(p.q[:, -2, :].reshape(-1).copy())
+        self.msg[2 * n:] = self.torch.tensor([e, v2, c2, fl, 0, 0, 0, 0], dtype=self.torch.float64)
 
-    def commit(self, gathered, honor_stop):
+    def commit(self, gathered, honor_stop, rank_lo, rank_hi):
         p = self.p
-        ny2 = p.q.shape[2]
-        if self.kinds[0]:
-            p.q[:, 0, :] = self.bufs[2].numpy().reshape(3, ny2)
-        if self.kinds[1]:
-            p.q[:, -1, :] = self.bufs[3].numpy().reshape(3, ny2)
-        g = gathered.numpy().reshape(-1, 8)
+        ny2, n = p.q.shape[2], self.rowlen
+        all_msgs = gathered.numpy().reshape(-1, 2 * n + 8)
+        if self.kinds[0] and rank_lo >= 0:
+            p.q[:, 0, :] = all_msgs[rank_lo, n:2 * n].reshape(3, ny2)       # the lower neighbour's LAST row
+        if self.kinds[1] and rank_hi >= 0:
+            p.q[:, -1, :] = all_msgs[rank_hi, :n].reshape(3, ny2)           # the upper neighbour's FIRST row
+        g = all_msgs[:, 2 * n:]
         ekin, v2, c2 = 0.0, 0.0, 0.0
         for r in g:                                         # rank order, like k_commit_gathered
             ekin += r[0]
