@@ -94,7 +94,12 @@ def _pin_hip_runtime():
     ("No HIP GPUs are available").  The slab path needs torch.distributed next to this library, so when
     torch is installed its bundled runtime is mapped first -- without importing torch."""
     import sys
-    if 'torch' in sys.modules or os.environ.get('GPF_SYSTEM_HIP') == '1':
+    if os.environ.get('GPF_SYSTEM_HIP') == '1':
+        return
+    if 'torch' in sys.modules:
+        blas = os.path.join(os.path.dirname(sys.modules['torch'].__file__), 'lib', 'librocblas.so')
+        if os.path.exists(blas):
+            os.environ.setdefault('GPF_ROCBLAS_PATH', blas)
         return
     try:
         import importlib.util
@@ -103,9 +108,14 @@ def _pin_hip_runtime():
         spec = None
     if spec is None or not spec.submodule_search_locations:
         return
-    cand = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], 'lib')
+    cand = os.path.join(libdir, 'libamdhip64.so')
     if os.path.exists(cand):
         C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        # rocBLAS (GP variance solve) must come from the same bundle, or a later `import torch` crashes
+        blas = os.path.join(libdir, 'librocblas.so')
+        if os.path.exists(blas):
+            os.environ.setdefault('GPF_ROCBLAS_PATH', blas)
 
 
 def load():

@@ -49,7 +49,8 @@ struct gpf_handle {
     double* q[2] = {nullptr, nullptr};      // ping-pong, 3 planes each
     double* topo = nullptr;                 // 3 planes
     double* Ls = nullptr;                   // 1 plane (allocated on first non-zero upload)
-    double* g1 = nullptr;                   // g1x [3][pitch] followed by g1y [3][Nx+2]
+    double* g1 = nullptr;                   // g1x [3][pitch], g1y [3][Nx+2] finished stage-1 ghost values; then arx [6][pitch], ary [6][Nx+2]
+    bool prepass_valid = false;             // g1 already holds the data of the next step (written by k_edge)
     double* seam = nullptr;                 // [2 edges][2 rows][4: h,hx,hy,Ls][pitch]
     bool has_seam[2] = {false, false};
     double* halo = nullptr;                 // this slab's all-gather message: first row, last row (3 x pitch each), 8-double record
@@ -245,7 +246,7 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
     }
     HIP_TRY_C(hipMalloc(&h->topo, 3 * plane_b));
     HIP_TRY_C(hipMemset(h->topo, 0, 3 * plane_b));
-    const size_t g1n = (size_t)3 * L.pitch + (size_t)3 * (L.Nx + 2);
+    const size_t g1n = (size_t)9 * L.pitch + (size_t)9 * (L.Nx + 2);
     HIP_TRY_C(hipMalloc(&h->g1, g1n * sizeof(double)));
     HIP_TRY_C(hipMemset(h->g1, 0, g1n * sizeof(double)));
     HIP_TRY_C(hipMalloc(&h->st, sizeof(StepState)));
@@ -344,6 +345,7 @@ extern "C" int gpf_upload(gpf_handle* h, int field, const double* host, size_t c
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (field == GPF_FIELD_Q) h->has_q = true;
     if (field == GPF_FIELD_TOPO) h->has_topo = true;
+    h->prepass_valid = false;
     return GPF_OK;
 }
 
@@ -510,6 +512,7 @@ extern "C" int gpf_pre_run(gpf_handle* h) {
     s.dt = c.adaptive ? c.CFL * dt_crit : c.dt_fixed;
     GPF_TRY(write_state(h, s));
     h->pre_run_done = true;
+    h->prepass_valid = false;
     h->host_step = 0; h->next_step = 0;
     return GPF_OK;
 }
@@ -580,26 +583,39 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
             g.seam[e] = h->seam + (size_t)e * 8 * L.pitch;
         }
     }
-    g.g1x = h->g1; g.g1y = h->g1 + 3 * L.pitch; g.st = h->st; g.L = L; g.E = h->E; g.honor_stop = honor_stop;
+    g.g1x = h->g1; g.g1y = h->g1 + 3 * L.pitch;
+    g.arx = h->g1 + 3 * L.pitch + 3 * (L.Nx + 2); g.ary = g.arx + 6 * L.pitch;
+    g.st = h->st; g.L = L; g.E = h->E; g.honor_stop = honor_stop;
     FinishArgs f;
     f.partials = h->partials; f.npartials = np_step + h->nghost_blocks; f.st = h->st;
     GhostFillArgs gf;
     gf.qa = h->q[0]; gf.qb = h->q[1]; gf.st = h->st; gf.partials = h->partials + np_step;
     gf.L = L; gf.E = h->E; gf.honor_stop = honor_stop;
     f.log = h->log; f.log_base = log_base; f.log_cap = h->log_cap; f.out = slab_out; f.honor_stop = honor_stop;
+    f.arx = g.arx; f.ary = g.ary; f.g1x = g.g1x; f.g1y = g.g1y; f.L = L; f.E = h->E; f.convert = slab_out ? 0 : 1;
 
     const int gmax = std::max(L.Nx, L.Ny);
     const dim3 ggrid((gmax + 255) / 256, 2), sgrid((h->nstrips + 3) / 4, h->nchunks);
     const step_kernel_t kstep = step_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, D);
+    const bool slab = slab_out != nullptr;
+    const int nprep = (L.Nx + L.Ny + 255) / 256;
     EOS_DISPATCH(h->cfg.eos, {
-        if (h->Ls) hipLaunchKernelGGL((k_ghost_stage1<EOS_, true>), ggrid, dim3(256), 0, h->stream, g, h->P);
-        else hipLaunchKernelGGL((k_ghost_stage1<EOS_, false>), ggrid, dim3(256), 0, h->stream, g, h->P);
+        if (slab || !h->prepass_valid) {     // stage-1 ghost data from the stored field
+            if (h->Ls) hipLaunchKernelGGL((k_ghost_stage1<EOS_, true>), ggrid, dim3(256), 0, h->stream, g, h->P);
+            else hipLaunchKernelGGL((k_ghost_stage1<EOS_, false>), ggrid, dim3(256), 0, h->stream, g, h->P);
+        }
         if (ev0) hipEventRecord(ev0, h->stream);
         hipLaunchKernelGGL(kstep, sgrid, dim3(256), 0, h->stream, a, h->P);
         if (ev1) hipEventRecord(ev1, h->stream);
-        hipLaunchKernelGGL((k_ghost_fill<EOS_>), dim3(h->nghost_blocks), dim3(256), 0, h->stream, gf, h->P);
+        if (slab) {
+            hipLaunchKernelGGL((k_ghost_fill<EOS_>), dim3(h->nghost_blocks), dim3(256), 0, h->stream, gf, h->P);
+        } else {                            // ghost cells of this step + stage-1 ghost data of the next one
+            if (h->Ls) hipLaunchKernelGGL((k_edge<EOS_, true>), dim3(h->nghost_blocks + nprep), dim3(256), 0, h->stream, g, gf.partials, h->nghost_blocks, h->P);
+            else hipLaunchKernelGGL((k_edge<EOS_, false>), dim3(h->nghost_blocks + nprep), dim3(256), 0, h->stream, g, gf.partials, h->nghost_blocks, h->P);
+        }
     });
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, h->stream, f);
+    h->prepass_valid = !slab;
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, h->stream, f);
     HIP_TRY(hipGetLastError());
     return GPF_OK;
 }
@@ -1118,6 +1134,7 @@ extern "C" int gpf_open_step(gpf_handle* h) {
     hipLaunchKernelGGL(k_copy3, dim3(blocks_for(3 * L.plane)), dim3(256), 0, h->stream, h->q[s.parity], h->q[s.parity ^ 1], 3 * L.plane);
     HIP_TRY(hipGetLastError());
     h->step_open = true;
+    h->prepass_valid = false;
     h->host_step = s.step; h->next_step = s.step;
     return GPF_OK;
 }

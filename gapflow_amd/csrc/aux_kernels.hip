@@ -200,12 +200,9 @@ struct GhostFillArgs {
 };
 
 template <int EOS>
-__global__ __launch_bounds__(256) void k_ghost_fill(const GhostFillArgs a, const Phys P) {
-    __shared__ Acc sm[4];
-    const StepState* st = a.st;
-    if (st->invalid != 0 || (a.honor_stop && (st->converged || st->step >= st->max_it))) return;
+__device__ __forceinline__ void ghost_fill_block(const GhostFillArgs& a, const Phys& P, int block, int nblocks, Acc* sm) {
     const Layout& L = a.L;
-    double* q = st->parity ? a.qa : a.qb;      // the buffer k_step has just written
+    double* q = a.st->parity ? a.qa : a.qb;      // the buffer k_step has just written
     Acc acc; acc.zero();
     auto put = [&](int ix, int iy, const double v[3], double w) {
         const long long o = L.at(ix, iy);
@@ -214,7 +211,7 @@ __global__ __launch_bounds__(256) void k_ghost_fill(const GhostFillArgs a, const
     };
     // work items: [0, 2*(Ny+2)) ghost rows incl. corners, then [.., + 2*Nx) ghost columns of interior rows
     const int nrow = 2 * (L.Ny + 2), ncol = 2 * L.Nx;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nrow + ncol; t += gridDim.x * blockDim.x) {
+    for (int t = block * blockDim.x + threadIdx.x; t < nrow + ncol; t += nblocks * blockDim.x) {
         double v[3];
         if (t < nrow) {
             const int e = t / (L.Ny + 2), iy = t % (L.Ny + 2);
@@ -246,8 +243,40 @@ __global__ __launch_bounds__(256) void k_ghost_fill(const GhostFillArgs a, const
     if (threadIdx.x == 0) {
         Partial p;
         p.ekin = acc.ekin; p.vmax2 = acc.v2; p.c2max = acc.c2; p.flags = (double)acc.flags;
-        a.partials[blockIdx.x] = p;
+        a.partials[block] = p;
     }
+}
+
+template <int EOS>
+__global__ __launch_bounds__(256) void k_ghost_fill(const GhostFillArgs a, const Phys P) {
+    __shared__ Acc sm[4];
+    const StepState* st = a.st;
+    if (st->invalid != 0 || (a.honor_stop && (st->converged || st->step >= st->max_it))) return;
+    ghost_fill_block<EOS>(a, P, blockIdx.x, gridDim.x, sm);
+}
+
+// Edge work of one step of an undivided problem, in ONE launch: blocks [0, nfill) write the ghost cells of the new
+// field (k_ghost_fill's job), the others prepare the stage-1 ghost data of the NEXT step from the same new field,
+// deriving any ghost value they need from the interior by the ghost rules -- the two jobs share no data.
+template <int EOS, bool HAS_LS>
+__global__ __launch_bounds__(256) void k_edge(const GhostArgs g, Partial* partials, int nfill, const Phys P) {
+    __shared__ Acc sm[4];
+    const StepState* st = g.st;
+    if (st->invalid != 0 || (g.honor_stop && (st->converged || st->step >= st->max_it))) return;
+    if ((int)blockIdx.x < nfill) {
+        GhostFillArgs f;
+        f.qa = const_cast<double*>(g.qa); f.qb = const_cast<double*>(g.qb); f.st = st; f.partials = partials;
+        f.L = g.L; f.E = g.E; f.honor_stop = g.honor_stop;
+        ghost_fill_block<EOS>(f, P, blockIdx.x, nfill, sm);
+        return;
+    }
+    const Layout& L = g.L;
+    FilledField fld;
+    fld.q = st->parity ? g.qa : g.qb; fld.L = L; fld.E = g.E;
+    const int D = direction_of_step(st, st->step + 1);
+    const int t = (blockIdx.x - nfill) * blockDim.x + threadIdx.x;
+    if (t < L.Ny) ghost_stage1_row<EOS, HAS_LS, false>(fld, g, P, D, t + 1);
+    else if (t - L.Ny < L.Nx) ghost_stage1_col<EOS, HAS_LS, false>(fld, g, P, D, t - L.Ny + 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -260,10 +289,14 @@ struct FinishArgs {
     LogEntry* log; long long log_base, log_cap;
     double* out;            // if non-null: slab mode, write the 8-double local record here instead of committing
     int honor_stop;
+    // (q, R) pairs parked by k_edge for the next step -> finished stage-1 ghost values, once dt is committed
+    const double* arx; const double* ary; double* g1x; double* g1y;
+    Layout L; Edges E;
+    int convert;
 };
 
-__global__ __launch_bounds__(256) void k_finish(const FinishArgs a) {
-    __shared__ Acc sm[4];
+__global__ __launch_bounds__(1024) void k_finish(const FinishArgs a) {
+    __shared__ Acc sm[16];
     StepState* st = a.st;
     if (st->invalid != 0 || (a.honor_stop && (st->converged || st->step >= st->max_it))) return;
     Acc acc; acc.zero();
@@ -284,6 +317,34 @@ __global__ __launch_bounds__(256) void k_finish(const FinishArgs a) {
         } else {
             commit_step(st, acc.ekin, acc.v2, acc.c2, acc.flags, a.log, a.log_base, a.log_cap);
         }
+    }
+    if (!a.convert) return;
+    __threadfence_block();
+    __syncthreads();                // thread 0's commit (dt, step) is visible to the block
+    if (st->invalid) return;
+    const double dt = st->dt;
+    const int D = direction_of_step(st, st->step);          // the step that will consume these values
+    const int ex = D > 0 ? 1 : 0, ey = D > 0 ? 3 : 2;
+    const Layout& L = a.L;
+    const double* __restrict__ arx = a.arx;
+    const double* __restrict__ ary = a.ary;
+    double* __restrict__ g1x = a.g1x;
+    double* __restrict__ g1y = a.g1y;
+    // rules hoisted out of the loops: 1 = Dirichlet (2 T - v), else copy
+    double sgn_x[3], add_x[3], sgn_y[3], add_y[3];
+    for (int c = 0; c < 3; ++c) {
+        const bool dx_ = a.E.rule[ex][c] == BC_D, dy_ = a.E.rule[ey][c] == BC_D;
+        sgn_x[c] = dx_ ? -1.0 : 1.0; add_x[c] = dx_ ? 2.0 * a.E.value[ex] : 0.0;
+        sgn_y[c] = dy_ ? -1.0 : 1.0; add_y[c] = dy_ ? 2.0 * a.E.value[ey] : 0.0;
+    }
+    for (int c = 0; c < 3; ++c) {
+        const int bx = c * L.pitch + L.off + 1, by = c * (L.Nx + 2) + 1;
+#pragma unroll 4
+        for (int i = threadIdx.x; i < L.Ny; i += blockDim.x)
+            g1x[bx + i] = add_x[c] + sgn_x[c] * (arx[bx + i] - dt * arx[bx + i + 3 * L.pitch]);
+#pragma unroll 4
+        for (int i = threadIdx.x; i < L.Nx; i += blockDim.x)
+            g1y[by + i] = add_y[c] + sgn_y[c] * (ary[by + i] - dt * ary[by + i + 3 * (L.Nx + 2)]);
     }
 }
 

@@ -269,7 +269,9 @@ inline RocLibs& roclibs() {
     static bool tried = false;
     if (tried) return R;
     tried = true;
-    void* hb = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
+    void* hb = nullptr;
+    if (const char* path = getenv("GPF_ROCBLAS_PATH")) hb = dlopen(path, RTLD_NOW | RTLD_GLOBAL);   // the copy PyTorch bundles
+    if (!hb) hb = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
     if (!hb) hb = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
     if (!hb) hb = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
     if (!hb) { R.err = "could not dlopen rocBLAS"; return R; }

@@ -60,15 +60,21 @@ struct StepArgs {
     int honor_stop;
 };
 
+// value a ghost cell of edge e takes from its source cell's value v (problem.py:758-766)
+__device__ __forceinline__ double ghost_rule(const Edges& E, int e, int c, double v) {
+    return E.rule[e][c] == BC_D ? 2.0 * E.value[e] - v : v;
+}
+
 __device__ __forceinline__ bool halted(const StepState* st, int honor_stop) {
     return st->invalid != 0 || (honor_stop && (st->converged || st->step >= st->max_it));
 }
 
-// direction of the predictor for the step about to run (problem.py:521-522)
-__device__ __forceinline__ int predictor_direction(const StepState* st) {
-    if (st->mc_order == 0) return (st->step % 2 == 0) ? 1 : -1;
+// direction of the predictor of step number `step` (problem.py:521-522)
+__device__ __forceinline__ int direction_of_step(const StepState* st, long long step) {
+    if (st->mc_order == 0) return (step % 2 == 0) ? 1 : -1;
     return ((st->mc_order + 1) / 2) ? 1 : -1;      // [[-1,1],[1,-1]][(switch+1)//2]
 }
+__device__ __forceinline__ int predictor_direction(const StepState* st) { return direction_of_step(st, st->step); }
 
 template <int EOS, bool HAS_LS, bool PIEZO, int D>
 __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, const double* __restrict__ qin,
@@ -224,33 +230,64 @@ __global__ __launch_bounds__(256) void k_step(const StepArgs a, const Phys P) {
 //   periodic : q1(ghost) = q1(partner), partner = first interior cell on the other side
 //   Neumann  : q1(ghost) = q1(adjacent)                (problem.py:766)
 //   Dirichlet: q1(ghost) = 2*target - q1(adjacent)     (problem.py:758-764)
-// q1 at the source cell is the ordinary predictor result there, from the stored field.
+// q1 at the source cell is the ordinary predictor result there: q1 = q - dt R.  k_step reads finished ghost values
+// g1 = rule(q - dt R).  The stand-alone prepass writes them directly; in the steady loop the dt-independent pair
+// (q, R) of step n+1 is computed as soon as the field of step n is complete -- before its dt is known -- in the
+// same launch as the ghost fill of step n (k_edge), and k_finish turns it into g1 once it has committed dt.
 // ---------------------------------------------------------------------------------------------
 struct GhostArgs {
     const double* qa; const double* qb;
     const double* topo; const double* Ls;
     const double* seam[2];      // per x edge: [2 rows][4: h,hx,hy,Ls][pitch] = topography of (source row, its
                                 // upwind row) on the far side of a periodic slab seam, or nullptr
-    double* g1x; double* g1y;
+    double* g1x; double* g1y;   // finished ghost values [3][pitch], [3][Nx+2]
+    double* arx; double* ary;   // (q, R) pairs [6][pitch], [6][Nx+2] awaiting dt
     const StepState* st;
     Layout L; Edges E;
     int honor_stop;
 };
 
-template <int EOS, bool HAS_LS>
-__device__ __forceinline__ void stage1_at(const double* __restrict__ q, const GhostArgs& a, const Phys& P, int D,
-                                          int ix, int iy, const double* tsrc, const double* tup, const double* lsrc,
-                                          const double* lup, int ixq_up, double dt, double out[3]) {
+// The field as it is stored, ghost cells included (they may be stale after a user edit: that is what the
+// reference's first stage would read, tests/test_wave_decay.py:101).
+struct StoredField {
+    const double* q; Layout L;
+    __device__ __forceinline__ double get(int ix, int iy, int c) const { return q[c * L.plane + L.at(ix, iy)]; }
+};
+// The interior of a freshly written field with its physical ghost cells derived on the fly by the ghost rules
+// (x rule, then y rule: the reference's order, so corners agree) -- what k_ghost_fill is writing concurrently.
+struct FilledField {
+    const double* q; Layout L; Edges E;
+    __device__ __forceinline__ double get(int ix, int iy, int c) const {
+        int sx = ix, sy = iy, ex = -1, ey = -1;
+        if (ix == 0 || ix == L.Nx + 1) {
+            ex = ix == 0 ? 0 : 1;
+            sx = E.rule[ex][0] == BC_P ? (ex == 0 ? L.Nx : 1) : (ex == 0 ? 1 : L.Nx);
+        }
+        if (iy == 0 || iy == L.Ny + 1) {
+            ey = iy == 0 ? 2 : 3;
+            sy = E.rule[ey][0] == BC_P ? (ey == 2 ? L.Ny : 1) : (ey == 2 ? 1 : L.Ny);
+        }
+        double v = q[c * L.plane + L.at(sx, sy)];
+        if (ex >= 0) v = ghost_rule(E, ex, c, v);
+        if (ey >= 0) v = ghost_rule(E, ey, c, v);
+        return v;
+    }
+};
+
+template <int EOS, bool HAS_LS, class Field>
+__device__ __forceinline__ void stage1_rate(const Field& fld, const GhostArgs& a, const Phys& P, int D, int ix, int iy,
+                                            const double* tsrc, const double* tup, const double* lsrc, const double* lup,
+                                            int ixq_up, double A[3], double R[3]) {
     // (ix, iy): source cell; x-upwind neighbour is (ix - D, iy) -- or row ixq_up of q when the caller
     // redirects it across a slab seam; y-upwind neighbour is (ix, iy - D).  tsrc/tup: optional topo rows.
     const Layout& L = a.L;
     auto cell = [&](int cx_, int cy_, const double* trow, const double* lrow, CellIn& c) {
-        const long long o = L.at(cx_, cy_);
-        c.rho = q[o]; c.jx = q[o + L.plane]; c.jy = q[o + 2 * L.plane];
+        c.rho = fld.get(cx_, cy_, 0); c.jx = fld.get(cx_, cy_, 1); c.jy = fld.get(cx_, cy_, 2);
         if (trow) {
             c.h = trow[L.off + cy_]; c.hx = trow[L.pitch + L.off + cy_]; c.hy = trow[2 * L.pitch + L.off + cy_];
             c.Ls = (HAS_LS && lrow) ? lrow[L.off + cy_] : 0.0;
         } else {
+            const long long o = L.at(cx_, cy_);
             c.h = a.topo[o]; c.hx = a.topo[o + L.plane]; c.hy = a.topo[o + 2 * L.plane];
             c.Ls = HAS_LS ? a.Ls[o] : 0.0;
         }
@@ -264,63 +301,80 @@ __device__ __forceinline__ void stage1_at(const double* __restrict__ q, const Gh
     cell_closure<EOS, false, HAS_LS, true>(cxu, P, fxu);
     cell_closure<EOS, false, HAS_LS, true>(cyu, P, fyu);
     const double cx = (double)D * P.inv_dx, cy = (double)D * P.inv_dy;
-    out[0] = c.rho - dt * (cx * (c.jx - cxu.jx) + cy * (c.jy - cyu.jy) - f.s0);
-    out[1] = c.jx - dt * (cx * (f.fx1 - fxu.fx1) + cy * (f.fx2 - fyu.fx2) - f.s1);
-    out[2] = c.jy - dt * (cx * (f.fx2 - fxu.fx2) + cy * (f.fy2 - fyu.fy2) - f.s2);
+    A[0] = c.rho; A[1] = c.jx; A[2] = c.jy;
+    R[0] = cx * (c.jx - cxu.jx) + cy * (c.jy - cyu.jy) - f.s0;
+    R[1] = cx * (f.fx1 - fxu.fx1) + cy * (f.fx2 - fyu.fx2) - f.s1;
+    R[2] = cx * (f.fx2 - fxu.fx2) + cy * (f.fy2 - fyu.fy2) - f.s2;
 }
 
+// one interior column iy of the downwind ghost ROW
+// FINAL: write rule(q - dt R) into g1 (dt known); otherwise park (q, R) in ar
+template <int EOS, bool HAS_LS, bool FINAL, class Field>
+__device__ __forceinline__ void ghost_stage1_row(const Field& fld, const GhostArgs& a, const Phys& P, int D, int iy) {
+    const Layout& L = a.L;
+    const int edge = D > 0 ? 1 : 0;
+    if (a.E.halo[edge] == 1) return;           // a neighbour's real cell: the stencil computes it
+    const bool periodic = a.E.rule[edge][0] == BC_P;
+    int ix_src, ix_up;
+    const double *ts = nullptr, *tu = nullptr, *ls = nullptr, *lu = nullptr;
+    if (!periodic) {
+        ix_src = D > 0 ? L.Nx : 1;
+        ix_up = ix_src - D;
+    } else if (a.E.halo[edge] != 2) {
+        ix_src = D > 0 ? 1 : L.Nx;              // partner cell on the other side of the domain
+        ix_up = ix_src - D;
+    } else {
+        // periodic seam between slabs: the partner row's q sits in this slab's halo/ghost row,
+        // its upwind neighbour is this slab's last interior row; their topography is static data
+        ix_src = D > 0 ? L.Nx + 1 : 0;
+        ix_up = D > 0 ? L.Nx : 1;
+        ts = a.seam[edge]; tu = a.seam[edge] + 4 * L.pitch;
+        ls = ts + 3 * L.pitch; lu = tu + 3 * L.pitch;
+    }
+    double A[3], R[3];
+    stage1_rate<EOS, HAS_LS>(fld, a, P, D, ix_src, iy, ts, tu, ls, lu, ix_up, A, R);
+    for (int c = 0; c < 3; ++c) {
+        if (FINAL) {
+            a.g1x[c * L.pitch + L.off + iy] = ghost_rule(a.E, edge, c, A[c] - a.st->dt * R[c]);
+        } else {
+            a.arx[c * L.pitch + L.off + iy] = A[c];
+            a.arx[(3 + c) * L.pitch + L.off + iy] = R[c];
+        }
+    }
+}
+
+// one interior row ix of the downwind ghost COLUMN
+template <int EOS, bool HAS_LS, bool FINAL, class Field>
+__device__ __forceinline__ void ghost_stage1_col(const Field& fld, const GhostArgs& a, const Phys& P, int D, int ix) {
+    const Layout& L = a.L;
+    const int edge = D > 0 ? 3 : 2;
+    const bool periodic = a.E.rule[edge][0] == BC_P;
+    const int iy_src = periodic ? (D > 0 ? 1 : L.Ny) : (D > 0 ? L.Ny : 1);
+    double A[3], R[3];
+    stage1_rate<EOS, HAS_LS>(fld, a, P, D, ix, iy_src, nullptr, nullptr, nullptr, nullptr, ix - D, A, R);
+    for (int c = 0; c < 3; ++c) {
+        if (FINAL) {
+            a.g1y[c * (L.Nx + 2) + ix] = ghost_rule(a.E, edge, c, A[c] - a.st->dt * R[c]);
+        } else {
+            a.ary[c * (L.Nx + 2) + ix] = A[c];
+            a.ary[(3 + c) * (L.Nx + 2) + ix] = R[c];
+        }
+    }
+}
+
+// stand-alone prepass from the STORED field: first step after an upload, and every step of a slab
 template <int EOS, bool HAS_LS>
 __global__ __launch_bounds__(256) void k_ghost_stage1(const GhostArgs a, const Phys P) {
     if (halted(a.st, a.honor_stop)) return;
     const Layout& L = a.L;
-    const double* q = a.st->parity ? a.qb : a.qa;
+    StoredField fld;
+    fld.q = a.st->parity ? a.qb : a.qa; fld.L = L;
     const int D = predictor_direction(a.st);
-    const double dt = a.st->dt;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    double v[3];
     if (blockIdx.y == 0) {
-        // downwind ghost ROW, interior columns
-        const int edge = D > 0 ? 1 : 0;
-        if (a.E.halo[edge] == 1) return;       // a neighbour's real cell: the stencil computes it
-        const int iy = t + 1;
-        if (iy > L.Ny) return;
-        const bool periodic = a.E.rule[edge][0] == BC_P;
-        // source row in the stored field
-        int ix_src, ix_up;
-        const double *ts = nullptr, *tu = nullptr, *ls = nullptr, *lu = nullptr;
-        if (!periodic) {
-            ix_src = D > 0 ? L.Nx : 1;
-            ix_up = ix_src - D;
-        } else if (a.E.halo[edge] != 2) {
-            ix_src = D > 0 ? 1 : L.Nx;              // partner cell on the other side of the domain
-            ix_up = ix_src - D;
-        } else {
-            // periodic seam between slabs: the partner row's q sits in this slab's halo/ghost row,
-            // its upwind neighbour is this slab's last interior row; their topography is static data
-            ix_src = D > 0 ? L.Nx + 1 : 0;
-            ix_up = D > 0 ? L.Nx : 1;
-            ts = a.seam[edge]; tu = a.seam[edge] + 4 * L.pitch;
-            ls = ts + 3 * L.pitch; lu = tu + 3 * L.pitch;
-        }
-        stage1_at<EOS, HAS_LS>(q, a, P, D, ix_src, iy, ts, tu, ls, lu, ix_up, dt, v);
-        for (int c = 0; c < 3; ++c) {
-            const int r = a.E.rule[edge][c];
-            const double g = (r == BC_D) ? 2.0 * a.E.value[edge] - v[c] : v[c];
-            a.g1x[c * L.pitch + L.off + iy] = g;
-        }
+        if (t + 1 <= L.Ny) ghost_stage1_row<EOS, HAS_LS, true>(fld, a, P, D, t + 1);
     } else {
-        // downwind ghost COLUMN, interior rows
-        const int edge = D > 0 ? 3 : 2;
-        const int ix = t + 1;
-        if (ix > L.Nx) return;
-        const bool periodic = a.E.rule[edge][0] == BC_P;
-        const int iy_src = periodic ? (D > 0 ? 1 : L.Ny) : (D > 0 ? L.Ny : 1);
-        stage1_at<EOS, HAS_LS>(q, a, P, D, ix, iy_src, nullptr, nullptr, nullptr, nullptr, ix - D, dt, v);
-        for (int c = 0; c < 3; ++c) {
-            const int r = a.E.rule[edge][c];
-            const double g = (r == BC_D) ? 2.0 * a.E.value[edge] - v[c] : v[c];
-            a.g1y[c * (L.Nx + 2) + ix] = g;
-        }
+        if (t + 1 <= L.Nx) ghost_stage1_col<EOS, HAS_LS, true>(fld, a, P, D, t + 1);
     }
 }
 
