@@ -18,6 +18,8 @@ EOS_KEYS = {'DH': ['rho0', 'P0', 'C1', 'C2'], 'PL': ['rho0', 'P0', 'alpha'], 'vd
 PIEZO_IDS = {'Barus': 1, 'Roelands': 2, 'Dukler': 3, 'McAdams': 4}
 PIEZO_KEYS = {'Barus': ['aB'], 'Roelands': ['mu_inf', 'p_ref', 'z'], 'Dukler': ['eta_v', 'rho_l', 'rho_v'],
               'McAdams': ['eta_v', 'rho_l', 'rho_v']}
+THINNING_IDS = {'Eyring': 1, 'Carreau': 2}
+THINNING_KEYS = {'Eyring': ['tauE'], 'Carreau': ['mu_inf', 'lam', 'a', 'N']}
 BC_P, BC_D, BC_N = 0, 1, 2
 FIELD_Q, FIELD_TOPO, FIELD_EXTRA, FIELD_PRESSURE, FIELD_TAU_AVG, FIELD_WALL_LOWER, FIELD_WALL_UPPER = range(7)
 FIELD_PRESSURE_VAR, FIELD_WALL_XZ_VAR, FIELD_WALL_YZ_VAR = 7, 8, 9
@@ -33,7 +35,8 @@ class GpfConfig(C.Structure):
                 ('bc_rule', (C.c_int32 * 3) * 4), ('bc_value', C.c_double * 4),
                 ('halo_lo', C.c_int32), ('halo_hi', C.c_int32),
                 ('adaptive', C.c_int32), ('CFL', C.c_double), ('dt_fixed', C.c_double), ('tol', C.c_double),
-                ('max_it', C.c_int64), ('mc_order', C.c_int32), ('device', C.c_int32)]
+                ('max_it', C.c_int64), ('mc_order', C.c_int32), ('device', C.c_int32),
+                ('thinning', C.c_int32), ('thinning_par', C.c_double * 4)]
 
 
 class GpfScalars(C.Structure):

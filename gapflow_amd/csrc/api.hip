@@ -155,6 +155,8 @@ static void make_phys(const gpf_config& c, Phys& P) {
     case GPF_PIEZO_DUKLER:
     case GPF_PIEZO_MCADAMS: P.pz[0] = z[0]; P.pz[1] = z[1]; P.pz[2] = z[2]; break;
     }
+    P.thinning = c.thinning;
+    for (int i = 0; i < 4; ++i) P.th[i] = c.thinning_par[i];
 }
 
 static int blocks_for(long long n, int bs = 256, int cap = 4096) {
@@ -196,6 +198,7 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
     if (cfg->Nx < 1 || cfg->Ny < 1) return fail(GPF_ERR_INVALID, "gpf_create: Nx, Ny must be >= 1");
     if (!(cfg->dx > 0) || !(cfg->dy > 0)) return fail(GPF_ERR_INVALID, "gpf_create: dx, dy must be > 0");
     if (cfg->eos < GPF_EOS_DH || cfg->eos > GPF_EOS_BAYADA) return fail(GPF_ERR_INVALID, "gpf_create: unknown EOS id");
+    if (cfg->thinning < 0 || cfg->thinning > GPF_THINNING_CARREAU) return fail(GPF_ERR_INVALID, "gpf_create: unknown shear-thinning id");
     for (int e = 0; e < 4; ++e) {
         int np = 0;
         for (int c = 0; c < 3; ++c) {
@@ -399,7 +402,11 @@ static int launch_fields(gpf_handle* h, const double* q) {
     const long long n = (long long)(L.Nx + 2) * (L.Ny + 2);
     FieldPtrs F = field_ptrs(h);
     EOS_DISPATCH(h->cfg.eos, {
-        if (h->Ls) hipLaunchKernelGGL((k_fields<EOS_, true>), dim3(blocks_for(n)), dim3(256), 0, h->stream, q, h->topo, h->Ls, F, L, h->P);
+        if (h->cfg.thinning != GPF_THINNING_NONE) {
+            hipLaunchKernelGGL((k_pressure<EOS_>), dim3(blocks_for(n)), dim3(256), 0, h->stream, q, F.p, L, h->P);
+            if (h->Ls) hipLaunchKernelGGL((k_fields_thinning<EOS_, true>), dim3(blocks_for(n)), dim3(256), 0, h->stream, q, h->topo, h->Ls, F, L, h->P, h->cfg.dx, h->cfg.dy);
+            else hipLaunchKernelGGL((k_fields_thinning<EOS_, false>), dim3(blocks_for(n)), dim3(256), 0, h->stream, q, h->topo, (const double*)nullptr, F, L, h->P, h->cfg.dx, h->cfg.dy);
+        } else if (h->Ls) hipLaunchKernelGGL((k_fields<EOS_, true>), dim3(blocks_for(n)), dim3(256), 0, h->stream, q, h->topo, h->Ls, F, L, h->P);
         else hipLaunchKernelGGL((k_fields<EOS_, false>), dim3(blocks_for(n)), dim3(256), 0, h->stream, q, h->topo, (const double*)nullptr, F, L, h->P);
     });
     HIP_TRY(hipGetLastError());
@@ -625,6 +632,8 @@ extern "C" int gpf_step(gpf_handle* h, int64_t n, int honor_stop, gpf_scalars_t*
     if (!h) return fail(GPF_ERR_INVALID, "null handle");
     if (!h->pre_run_done) return fail(GPF_ERR_STATE, "gpf_step: call gpf_pre_run first (Problem._pre_run, problem.py:412)");
     if (h->E.halo[0] || h->E.halo[1]) return fail(GPF_ERR_STATE, "gpf_step: this handle is a slab; use gpf_step_local / gpf_step_commit");
+    if (h->cfg.thinning != GPF_THINNING_NONE)
+        return fail(GPF_ERR_STATE, "gpf_step: shear thinning needs grad p (a wider stencil than the fused step has); use the stage-wise calls");
     if (n < 0) return fail(GPF_ERR_INVALID, "gpf_step: n < 0");
     HIP_TRY(hipSetDevice(h->cfg.device));
     int64_t done = 0, logged = 0;

@@ -446,6 +446,44 @@ __global__ __launch_bounds__(256) void k_fields(const double* q, const double* t
     }
 }
 
+// Shear thinning (stress.py:170-192, 314-326): two passes, because the viscosity of a cell needs grad p.
+// Pass 1 stores p; pass 2 forms np.gradient(p) (central differences, one-sided at the ends of the array
+// INCLUDING ghost cells), the thinned viscosity, and with it the stresses.
+template <int EOS>
+__global__ __launch_bounds__(256) void k_pressure(const double* q, double* p, Layout L, Phys P) {
+    const long long w = L.Ny + 2, n = (long long)(L.Nx + 2) * w;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long o = L.at((int)(i / w), (int)(i % w));
+        p[o] = eos_pressure<EOS>(q[o], P);
+    }
+}
+
+template <int EOS, bool HAS_LS>
+__global__ __launch_bounds__(256) void k_fields_thinning(const double* q, const double* topo, const double* Ls, FieldPtrs F,
+                                                         Layout L, Phys P, double dx, double dy) {
+    const long long w = L.Ny + 2, n = (long long)(L.Nx + 2) * w;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int ix = (int)(i / w), iy = (int)(i % w);
+        const long long o = L.at(ix, iy);
+        CellIn c;
+        c.rho = q[o]; c.jx = q[o + L.plane]; c.jy = q[o + 2 * L.plane];
+        c.h = topo[o]; c.hx = topo[o + L.plane]; c.hy = topo[o + 2 * L.plane];
+        c.Ls = HAS_LS ? Ls[o] : 0.0;
+        const double pc = F.p[o];
+        // np.gradient, edge_order 1
+        const int ixm = ix > 0 ? ix - 1 : ix, ixp = ix < L.Nx + 1 ? ix + 1 : ix;
+        const int iym = iy > 0 ? iy - 1 : iy, iyp = iy < L.Ny + 1 ? iy + 1 : iy;
+        const double dpx = (F.p[L.at(ixp, iy)] - F.p[L.at(ixm, iy)]) / ((ixp - ixm) * dx);
+        const double dpy = (F.p[L.at(ix, iyp)] - F.p[L.at(ix, iym)]) / ((iyp - iym) * dy);
+        const double mu0 = (P.piezo == PIEZO_NONE) ? P.eta : piezo_eta(P.eta, (EOS == EOS_BAYADA) ? c.rho : pc, P);
+        const double eta = thinning_eta(mu0, dpx, dpy, c.h, P);
+        CellFields f;
+        cell_fields<EOS>(c, P, f, eta);
+        for (int k = 0; k < 3; ++k) F.tau[o + k * L.plane] = f.tau[k];
+        for (int k = 0; k < 6; ++k) { F.lower[o + k * L.plane] = f.lower[k]; F.upper[o + k * L.plane] = f.upper[k]; }
+    }
+}
+
 // integrate.predictor_corrector: np.roll wraps over the whole (Nx+2)x(Ny+2) array (integrate.py:74-75)
 __global__ __launch_bounds__(256) void k_fluxdiff(const double* q, const double* p, const double* tau, int d, double* fx,
                                                   double* fy, Layout L) {

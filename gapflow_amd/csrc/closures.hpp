@@ -35,6 +35,7 @@ namespace gpf {
 
 enum { EOS_DH = 0, EOS_PL = 1, EOS_VDW = 2, EOS_MT = 3, EOS_CUBIC = 4, EOS_BWR = 5, EOS_BAYADA = 6 };
 enum { PIEZO_NONE = 0, PIEZO_BARUS = 1, PIEZO_ROELANDS = 2, PIEZO_DUKLER = 3, PIEZO_MCADAMS = 4 };
+enum { THIN_NONE = 0, THIN_EYRING = 1, THIN_CARREAU = 2 };
 
 // Material + kinematic constants, preprocessed on the host (see make_phys in api.hip).
 struct Phys {
@@ -45,6 +46,8 @@ struct Phys {
     double e[12];       // EOS constants, meaning per EOS documented in make_phys
     double x[32];       // BWR: temperature-folded polynomial coefficients
     double pz[4];       // piezo-viscosity constants
+    int thinning;
+    double th[4];       // shear-thinning constants: Eyring tauE | Carreau mu_inf, lam, a, N
 };
 
 // Reciprocal.  On gfx950 an IEEE f64 division expands to ~15 VALU instructions (div_scale, rcp,
@@ -168,6 +171,24 @@ GPF_HD double piezo_eta(double eta0, double arg, const Phys& P) {
     }
 }
 
+// Shear-thinning factor eta/mu0 at the mean wall shear rate of the Newtonian profile
+// (viscosity.py:69-141, 265-318; stress.py:314-324 passes U and V as the two wall velocities).
+GPF_HD double thinning_eta(double mu0, double dp_dx, double dp_dy, double h, const Phys& P) {
+    const double gp = hypot(dp_dx, dp_dy);
+    const double du_p = h * gp / (2.0 * mu0);
+    const double du_c = (P.V - P.U) / h;
+    const double rate = (fabs(du_p + du_c) + fabs(-du_p + du_c)) / 2.0;
+    if (P.thinning == THIN_EYRING) {
+        const double tau0 = mu0 * rate;
+        return mu0 * (P.th[0] / tau0 * asinh(tau0 / P.th[0]));
+    }
+    if (P.thinning == THIN_CARREAU) {
+        const double mu = P.th[0] + (mu0 - P.th[0]) * pow(1.0 + pow(P.th[1] * rate, P.th[2]), (P.th[3] - 1.0) / P.th[2]);
+        return mu0 * (mu / mu0);
+    }
+    return mu0;
+}
+
 // ---- one cell: fluxes and source ------------------------------------------------------------
 
 struct CellIn {
@@ -264,11 +285,13 @@ struct CellFields {
     double upper[6];
 };
 
+// eta_override >= 0: shear viscosity already evaluated by the caller (shear thinning needs grad p)
 template <int EOS>
-GPF_HD void cell_fields(const CellIn& c, const Phys& P, CellFields& o) {
+GPF_HD void cell_fields(const CellIn& c, const Phys& P, CellFields& o, double eta_override = -1.0) {
     const double U = P.U, V = P.V;
     const double p = eos_pressure<EOS>(c.rho, P);
-    const double eta = (P.piezo == PIEZO_NONE) ? P.eta : piezo_eta(P.eta, (EOS == EOS_BAYADA) ? c.rho : p, P);
+    const double eta = eta_override >= 0.0 ? eta_override
+                     : (P.piezo == PIEZO_NONE) ? P.eta : piezo_eta(P.eta, (EOS == EOS_BAYADA) ? c.rho : p, P);
     const double v1 = P.zeta + (4.0 / 3.0) * eta;
     const double v2 = P.zeta - (2.0 / 3.0) * eta;
     const double D = 4.0 * c.Ls + c.h;

@@ -182,8 +182,12 @@ class Problem:
             cfg.piezo = _lib.PIEZO_IDS[name]
             for i, k in enumerate(_lib.PIEZO_KEYS[name]):
                 cfg.piezo_par[i] = p['piezo'][k]
-        if 'thinning' in p:
-            raise NotImplementedError("shear thinning (GaPFlow/models/viscosity.py:69-96) is not on the fused path yet")
+        cfg.thinning = 0
+        if 'thinning' in p and p['thinning']['name'] in _lib.THINNING_IDS:
+            name = p['thinning']['name']
+            cfg.thinning = _lib.THINNING_IDS[name]
+            for i, k in enumerate(_lib.THINNING_KEYS[name]):
+                cfg.thinning_par[i] = p['thinning'][k]
         rules, values = self._edge_rules()
         for e in range(4):
             for c in range(3):
@@ -357,8 +361,8 @@ class Problem:
         """One MacCormack predictor-corrector time step (problem.py:509-569), on the device."""
         if self.step is None:
             raise RuntimeError("call _pre_run() (or run()) before update()")
-        if self._gp_models:
-            self._update_with_surrogates()
+        if self._gp_models or self._cfg.thinning:
+            self._update_with_surrogates()      # stage-wise pipeline (host between stages / grad p for thinning)
         else:
             self._advance(1, honor_stop=False)
 
@@ -422,7 +426,7 @@ class Problem:
         self._tic = datetime.now()
         wf = self.options['write_freq']
         try:
-            while self._gp_models and not self.converged and self.step < self.max_it and not self._stop:
+            while (self._gp_models or self._cfg.thinning) and not self.converged and self.step < self.max_it and not self._stop:
                 self.update()                   # surrogates: one host-driven step at a time
                 if self.step % wf == 0 and not silent and not self._stop:
                     self.write()

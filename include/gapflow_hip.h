@@ -50,6 +50,9 @@ enum { GPF_BC_PERIODIC = 0, GPF_BC_DIRICHLET = 1, GPF_BC_NEUMANN = 2 };
 enum { GPF_PIEZO_NONE = 0, GPF_PIEZO_BARUS = 1, GPF_PIEZO_ROELANDS = 2,
        GPF_PIEZO_DUKLER = 3, GPF_PIEZO_MCADAMS = 4 };
 
+/* Shear-thinning laws (GaPFlow/models/viscosity.py:69-96) */
+enum { GPF_THINNING_NONE = 0, GPF_THINNING_EYRING = 1, GPF_THINNING_CARREAU = 2 };
+
 /* Field ids for gpf_upload / gpf_download */
 enum {
     GPF_FIELD_Q = 0,          /* 3 comps: rho, jx, jy                 (problem.py:128)          */
@@ -94,6 +97,8 @@ typedef struct {
     int64_t max_it;
     int32_t mc_order;          /* +1, -1, or 0 = alternate by step parity (problem.py:521-522)     */
     int32_t device;            /* HIP device ordinal                                                */
+    int32_t thinning;          /* GPF_THINNING_*; only the stage-wise step supports it (needs grad p)  */
+    double  thinning_par[4];   /* Eyring: tauE | Carreau: mu_inf, lam, a, N                            */
 } gpf_config;
 
 /* Per-step scalars (problem.py:334-362, 571-586).  All sums/maxima run over the whole

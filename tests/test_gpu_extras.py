@@ -42,11 +42,46 @@ def test_piezoviscosity_steps_match_oracle(hiplib, eos, name, rho0, ny):
     np.testing.assert_allclose(gpu.bulk_stress.stress, cpu.tau_avg, rtol=1e-9, atol=1e-12 * np.abs(cpu.tau_avg).max())
 
 
-def test_shear_thinning_is_refused_not_approximated(hiplib):
+THINNING = """
+options: {{silent: True}}
+grid: {{Nx: 48, Ny: {ny}, Lx: 0.05, Ly: {ly}, xE: ['D', 'N', 'N'], xW: ['D', 'N', 'N'], xE_D: 877.7007, xW_D: 877.7007}}
+geometry: {{type: parabolic, hmin: 1.e-5, hmax: 4.e-5, U: 10., V: {v}}}
+numerics: {{CFL: 0.4, adaptive: 1, max_it: 100}}
+properties:
+    EOS: DH
+    shear: 0.05
+    bulk: 0.
+    rho0: 877.7007
+    thinning: {{name: {name}{extra}}}
+{piezo}
+"""
+
+
+@pytest.mark.parametrize('name,extra,ny,piezo', [('Eyring', ', tauE: 5.e5', 1, ''), ('Carreau', ', mu_inf: 1.e-3, lam: 1.e-5, a: 2., N: 0.6', 10, ''),
+                                                 ('Eyring', '', 10, '    piezo: {name: Barus}')])
+def test_shear_thinning_steps_match_oracle(hiplib, name, extra, ny, piezo):
+    """viscosity.py:69-141 with np.gradient(p) over the ghosted array (stress.py:170-192, 314-326): the stage-wise
+    pipeline (the fused step cannot see grad p) against the oracle, 15 steps."""
     from gapflow_amd import Problem
-    with pytest.raises(NotImplementedError):
-        Problem.from_string(PIEZO.format(eos='DH', name='Barus', rho0=877.7007, ny=1, ly=1., v=0.)
-                            + "    thinning: {name: Eyring}\n")
+    from oracle.problem import OracleProblem
+    text = THINNING.format(name=name, extra=extra, ny=ny, ly=0.01 if ny > 1 else 1., v=1. if ny > 1 else 0., piezo=piezo)
+    gpu, cpu = Problem.from_string(text), OracleProblem.from_string(text)
+    gpu._pre_run()
+    cpu._pre_run()
+    for _ in range(15):
+        gpu.update()
+        cpu.update()
+    assert gpu.step == 15
+    for c in range(3):
+        scale = np.abs(cpu.q[c]).max() or 1.
+        assert np.abs(gpu.q[c] - cpu.q[c]).max() <= 1e-9 * scale
+    np.testing.assert_allclose(gpu.dt, cpu.dt, rtol=1e-10)
+    cpu.update_closures()
+    np.testing.assert_allclose(gpu.bulk_stress.stress, cpu.tau_avg, rtol=1e-8, atol=1e-10 * np.abs(cpu.tau_avg).max())
+    # the fused entry point refuses such a problem instead of ignoring the thinning law
+    from gapflow_amd import _lib
+    import ctypes as C
+    assert gpu._lib.gpf_step(gpu._h, 1, 0, None, 0, C.byref(C.c_int64())) == -5
 
 
 def test_output_files_have_the_reference_layout(hiplib, tmp_path):

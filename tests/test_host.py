@@ -142,7 +142,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     from gapflow_amd import _lib
     # gpf_config: 2 i32, 6 f64, i32(+pad), 8 f64, i32(+pad), 4 f64, 12 i32, 4 f64, 2 i32, i32(+pad), 3 f64, i64, 2 i32
-    assert ctypes.sizeof(_lib.GpfConfig) == 8 + 48 + 8 + 64 + 8 + 32 + 48 + 32 + 8 + 8 + 24 + 8 + 8
+    assert ctypes.sizeof(_lib.GpfConfig) == 8 + 48 + 8 + 64 + 8 + 32 + 48 + 32 + 8 + 8 + 24 + 8 + 8 + 8 + 32
     assert ctypes.sizeof(_lib.GpfScalars) == 8 + 8 * 8 + 8
     assert _lib.GpfConfig.bc_rule.offset == 8 + 48 + 8 + 64 + 8 + 32
 
