@@ -85,7 +85,7 @@ def measured_traffic():
     return best if best else (None, None)
 
 
-def cpu_baseline(sample_n=1024, steps=4):
+def cpu_baseline(sample_n=2048, steps=10):
     """The oracle on a bounded sample: same YAML with Nx=Ny=sample_n, `steps` timed steps after one warm-up."""
     from oracle.problem import OracleProblem
     with contextlib.redirect_stdout(sys.stderr):

@@ -1,16 +1,20 @@
-"""``python -m gapflow_amd -i input.yaml`` (GaPFlow/__main__.py:28-48)."""
-from argparse import ArgumentParser
+"""Command line entry: ``python -m gapflow_amd -i input.yaml`` runs one problem to completion
+(same flag as the reference's ``python -m GaPFlow -i``, GaPFlow/__main__.py:28-48)."""
+import argparse
+import sys
 
 from . import Problem
 
 
-def get_parser():
-    parser = ArgumentParser()
-    required = parser.add_argument_group('required arguments')
-    required.add_argument('-i', '--input', dest="filename", help="YAML input file", required=True)
-    return parser
+def main(argv=None):
+    cli = argparse.ArgumentParser(prog='python -m gapflow_amd',
+                                  description="Advance a GaPFlow YAML problem on an MI355X.")
+    cli.add_argument('-i', '--input', dest='filename', required=True, metavar='YAML', help="problem definition")
+    cli.add_argument('--device', type=int, default=0, help="HIP device ordinal (default 0)")
+    opts = cli.parse_args(argv)
+    Problem.from_yaml(opts.filename).run()
+    return 0
 
 
 if __name__ == "__main__":
-    args = get_parser().parse_args()
-    Problem.from_yaml(args.filename).run()
+    sys.exit(main())
