@@ -429,7 +429,7 @@ extern "C" int gpf_update_closures(gpf_handle* h) {
 // ---------------------------------------------------------------------------------------------
 // scalars
 // ---------------------------------------------------------------------------------------------
-static int launch_scalars(gpf_handle* h, const double* q, ScalarPartial* total) {
+static int launch_scalars(gpf_handle* h, const double* q, ScalarPartial* total, bool need_sound_speed = true) {
     const Layout& L = h->L;
     const int row0 = h->E.halo[0] ? 1 : 0, row1 = h->E.halo[1] ? L.Nx : L.Nx + 1;
     const long long n = (long long)(row1 - row0 + 1) * (L.Ny + 2);
@@ -441,7 +441,7 @@ static int launch_scalars(gpf_handle* h, const double* q, ScalarPartial* total) 
     hipLaunchKernelGGL(k_scalars_final, dim3(1), dim3(256), 0, h->stream, h->spart, nb, total);
     HIP_TRY(hipGetLastError());
     // with a pressure surrogate the sound speed is the steepest slope of the GP mean (stress.py:533-537)
-    if (h->gp[0].set) GPF_TRY(gp_launch_mean(h, 0, q, true, &total->c2));
+    if (h->gp[0].set && need_sound_speed) GPF_TRY(gp_launch_mean(h, 0, q, true, &total->c2));
     return GPF_OK;
 }
 
@@ -1187,7 +1187,7 @@ extern "C" int gpf_close_step(gpf_handle* h, gpf_scalars_t* out) {
     hipLaunchKernelGGL(k_average, dim3(blocks_for(n)), dim3(256), 0, h->stream, q, q0, L);
     ScalarPartial* pre = h->spart + h->nspart;
     ScalarPartial* post = h->spart + h->nspart + 1;
-    GPF_TRY(launch_scalars(h, q, pre));                 // validity of the averaged field (problem.py:565)
+    GPF_TRY(launch_scalars(h, q, pre, false));          // validity of the averaged field only (problem.py:565)
     hipLaunchKernelGGL(k_bc_x, dim3((L.Ny + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
     hipLaunchKernelGGL(k_bc_y, dim3((L.Nx + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
     GPF_TRY(launch_scalars(h, q, post));                // scalars after the ghost update (problem.py:576-578)

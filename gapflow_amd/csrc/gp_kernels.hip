@@ -42,6 +42,41 @@ struct GpFieldArgs {
     double* blockmax;               // per-block max of d mean/d x_0 (WITH_GRAD) or nullptr
 };
 
+// Matern-3/2 pieces for t = 3 r^2 >= 0:  s = sqrt(t),  e = exp(-s);  k = A (1 + s) e,  dk/ds ~ s e.
+// The posterior-mean kernel runs at 98 % VALU issue (profiles/r01_c_gp), so the instruction count of this
+// function IS its speed: v_rsq_f64 + Goldschmidt instead of the range-scaled library sqrt, and a branch-free
+// exp (argument <= 0: round-to-nearest reduction by ln 2, degree-13 polynomial, v_ldexp_f64) instead of the
+// library exp with its overflow/underflow selects.  Both are accurate to ~1 ulp on the range that matters;
+// every kernel below (K, Ks, mean) uses this one function so that K and Ks stay consistent.
+__device__ __forceinline__ void matern_terms(double t, double& s, double& e) {
+    const double tt = fmax(t, 1e-300);                      // t = 0 -> s = 1e-150, k = A exactly
+    const double y = __builtin_amdgcn_rsq(tt);              // ~24-bit seed
+    double g = tt * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    s = fma(g, r, g);
+    const double x = -fmin(s, 800.0);                       // exp(-800) = 0 in fp64 anyway
+    const double n = __builtin_rint(x * 1.4426950408889634);
+    double f = fma(n, -0.69314718036912382, x);             // ln 2 = hi + lo, hi has 21 trailing zero bits
+    f = fma(n, -1.9082149292705877e-10, f);
+    double p = 1.6059043836821613e-10;                      // 1/13!
+    p = fma(p, f, 2.08767569878681e-09);                    // 1/12!
+    p = fma(p, f, 2.505210838544172e-08);                   // 1/11!
+    p = fma(p, f, 2.755731922398589e-07);                   // 1/10!
+    p = fma(p, f, 2.7557319223985893e-06);                  // 1/9!
+    p = fma(p, f, 2.48015873015873e-05);                    // 1/8!
+    p = fma(p, f, 1.984126984126984e-04);                   // 1/7!
+    p = fma(p, f, 1.388888888888889e-03);                   // 1/6!
+    p = fma(p, f, 8.333333333333333e-03);                   // 1/5!
+    p = fma(p, f, 4.1666666666666664e-02);                  // 1/4!
+    p = fma(p, f, 1.6666666666666666e-01);                  // 1/3!
+    p = fma(p, f, 0.5);
+    p = fma(p, f, 1.0);
+    p = fma(p, f, 1.0);
+    e = ldexp(p, (int)n);
+}
+
 __device__ __forceinline__ double gp_feature(const GpFieldArgs& a, int f, long long o) {
     if (f < 3) return a.q[o + f * a.L.plane];
     if (f < 6) return a.topo[o + (f - 3) * a.L.plane];
@@ -57,8 +92,9 @@ __global__ void k_gp_matrix(const double* Z, int n, int d, double amp, double si
         const double t = Z[i * d + k] - Z[j * d + k];
         r2 += t * t;
     }
-    const double r = sqrt(3.0 * r2);                  // sqrt3 * r
-    K[i + (long long)j * n] = amp * (1.0 + r) * exp(-r) + (i == j ? sigma2 : 0.0);
+    double r, e;                                      // r = sqrt3 * |dz|
+    matern_terms(3.0 * r2, r, e);
+    K[i + (long long)j * n] = amp * (1.0 + r) * e + (i == j ? sigma2 : 0.0);
 }
 
 // posterior mean (and optionally d mean/d x_0) at every cell of the grid incl. ghost cells
@@ -93,9 +129,9 @@ __global__ __launch_bounds__(256) void k_gp_mean(const GpModelDev g, const GpFie
                 if (k == 0) d0 = t;
                 r2 += t * t;
             }
-            const double r = sqrt(3.0 * r2);
-            const double e = exp(-r);
-            const double kv = (1.0 + r) * e;
+            double r, e;
+            matern_terms(3.0 * r2, r, e);
+            const double kv = fma(r, e, e);
             for (int k = 0; k < M; ++k) acc[k] += sA[k * cnt + i] * kv;
             if (WITH_GRAD) gacc += sA[i] * d0 * e;
         }
@@ -145,8 +181,9 @@ __global__ __launch_bounds__(256) void k_gp_ks_tile(const GpModelDev g, const Gp
         const double t = g.Z[(long long)i * D + k] - gp_feature(a, g.dims[k], o) * g.fscale[k];
         r2 += t * t;
     }
-    const double r = sqrt(3.0 * r2);
-    Ks[i + (long long)j * g.n] = g.amp * (1.0 + r) * exp(-r);
+    double r, e;
+    matern_terms(3.0 * r2, r, e);
+    Ks[i + (long long)j * g.n] = g.amp * (1.0 + r) * e;
 }
 
 // var_j = (A - sum_i V_ij^2) * yscale^2 for a solved tile V = L^-1 Ks; per-block max for the AL criterion
