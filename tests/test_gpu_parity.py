@@ -165,3 +165,37 @@ def test_invalid_state_rolls_back(hiplib):
     assert prob._stop
     assert prob.step == 1
     np.testing.assert_array_equal(prob.q, good)
+
+
+def test_one_dimensional_problem_along_y(hiplib):
+    """A 1-D problem laid along y (Nx = 1, flipped geometry, V-driven) is the transpose of the same problem along x:
+    exercises single-row chunks, partially filled strips and the y ghost rules of the fused kernel."""
+    import io
+    from copy import deepcopy
+    from gapflow_amd import Problem
+    from gapflow_amd.io import read_yaml_input
+    import reference_suite as rs
+    dx_ = read_yaml_input(io.StringIO(rs.JOURNAL_1D.replace('Nx: 100', 'Nx: 150').replace('C1: 3.5e12', 'C1: 3.5e10')))
+    dy_ = deepcopy(dx_)
+    g = dy_['grid']
+    g['Nx'], g['Ny'], g['dx'], g['dy'], g['Lx'], g['Ly'] = g['Ny'], g['Nx'], g['dy'], g['dx'], g['Ly'], g['Lx']
+    # the geometry is generated on the transposed grid and flipped back (topography.py:227-234)
+    gy = dy_['geometry']
+    gy['U'], gy['V'], gy['flip'] = 0., dx_['geometry']['U'], True
+    px = Problem._from_dict(dx_)
+    # flip=True transposes an (Nx+2, Ny+2) profile: build it from a problem whose grid is the x-layout, then swap
+    from gapflow_amd.topography import Topography
+    py = Problem(dy_['options'], dy_['grid'], dy_['numerics'], dy_['properties'], dict(gy, flip=False))
+    t = Topography(dx_['grid'], dx_['geometry'], dx_['properties']).full
+    py.topo.full[0], py.topo.full[1], py.topo.full[2] = t[0].T, t[2].T, t[1].T
+    py._upload_topo()
+    px._pre_run()
+    py._pre_run()
+    for _ in range(30):
+        px.update()
+        py.update()
+    np.testing.assert_allclose(px.dt, py.dt, rtol=1e-13)
+    for a, b in ((0, 0), (1, 2), (2, 1)):
+        x, y = px.q[a], py.q[b].T
+        scale = np.abs(x).max() or 1.
+        assert np.abs(x - y).max() <= 1e-9 * scale      # x and y terms associate differently; sensitivity ~1e-10 per step
