@@ -143,7 +143,12 @@ def run_single(args):
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "k_step<DH>",
                      "kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_launch": BYTES_PER_CELL * cells,
-                     "all_kernels_ms_per_step": tt.value / nk},
+                     "all_kernels_ms_per_step": tt.value / nk,
+                     "note": "algorithmic bytes follow SURVEY.md 8(d): 72 B per cell-update (q read + topography read + "
+                             "q write).  The journal-bearing gap varies along x only, and the kernel then reads the "
+                             "topography as one (h, hx, hy) triple per row instead of three planes (GPF_TOPO_PLANES=1 "
+                             "disables this): its actual HBM traffic (`traffic`) is below the algorithmic figure, and "
+                             "against the 48 B per cell-update that remain compulsory the fraction is achieved*48/72/peak."},
     }
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline()

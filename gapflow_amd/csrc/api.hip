@@ -48,6 +48,8 @@ struct gpf_handle {
     // device state
     double* q[2] = {nullptr, nullptr};      // ping-pong, 3 planes each
     double* topo = nullptr;                 // 3 planes
+    double* topo_line = nullptr;            // [3][max(Nx,Ny)+2]: the profile when the topography varies along one axis only
+    int topo_mode = 0;                      // 0: 2-D planes, 1: function of ix only, 2: function of iy only
     double* Ls = nullptr;                   // 1 plane (allocated on first non-zero upload)
     double* g1 = nullptr;                   // g1x [3][pitch], g1y [3][Nx+2] finished stage-1 ghost values; then arx [6][pitch], ary [6][Nx+2]
     bool prepass_valid = false;             // g1 already holds the data of the next step (written by k_edge)
@@ -270,7 +272,7 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
 extern "C" int gpf_destroy(gpf_handle* h) {
     if (!h) return GPF_OK;
     hipSetDevice(h->cfg.device);
-    void* ptrs[] = {h->q[0], h->q[1], h->topo, h->Ls, h->g1, h->seam, h->halo, h->st, h->partials, h->spart,
+    void* ptrs[] = {h->q[0], h->q[1], h->topo, h->topo_line, h->Ls, h->g1, h->seam, h->halo, h->st, h->partials, h->spart,
                     h->log, h->stage, h->fields, h->work, h->gpvar, h->gpscratch, h->gptile,
                     h->gp[0].Z, h->gp[0].alpha, h->gp[0].L, h->gp[1].Z, h->gp[1].alpha, h->gp[1].L,
                     h->gp[2].Z, h->gp[2].alpha, h->gp[2].L};
@@ -340,6 +342,32 @@ extern "C" int gpf_upload(gpf_handle* h, int field, const double* host, size_t c
         if (!h->Ls) { HIP_TRY(hipMalloc(&h->Ls, (size_t)L.plane * sizeof(double))); h->plan_valid = false; }
         HIP_TRY(hipMemsetAsync(h->Ls, 0, (size_t)L.plane * sizeof(double), h->stream));
         dst = h->Ls;
+    }
+    if (field == GPF_FIELD_TOPO) {
+        // does the topography vary along one axis only?  (bitwise test on the host array)
+        const int nx = L.Nx + 2, ny = L.Ny + 2;
+        bool xonly = true, yonly = true;
+        for (int c = 0; c < 3 && (xonly || yonly); ++c)
+            for (int ix = 0; ix < nx && (xonly || yonly); ++ix) {
+                const double* row = host + ((size_t)c * nx + ix) * ny;
+                const double* row0 = host + (size_t)c * nx * ny;
+                for (int iy = 0; iy < ny; ++iy) {
+                    if (std::memcmp(&row[iy], &row[0], 8) != 0) xonly = false;
+                    if (std::memcmp(&row[iy], &row0[iy], 8) != 0) yonly = false;
+                }
+            }
+        const int mode = xonly ? 1 : (yonly ? 2 : 0);
+        if (mode != h->topo_mode) h->plan_valid = false;
+        h->topo_mode = mode;
+        if (mode) {
+            const int n = mode == 1 ? nx : ny;
+            std::vector<double> line((size_t)3 * n);
+            for (int c = 0; c < 3; ++c)
+                for (int i = 0; i < n; ++i)
+                    line[(size_t)c * n + i] = mode == 1 ? host[((size_t)c * nx + i) * ny] : host[(size_t)c * nx * ny + i];
+            if (!h->topo_line) HIP_TRY(hipMalloc(&h->topo_line, (size_t)3 * (std::max(nx, ny)) * sizeof(double)));
+            HIP_TRY(hipMemcpy(h->topo_line, line.data(), line.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
     }
     GPF_TRY(ensure_stage(h, count));
     HIP_TRY(hipMemcpyAsync(h->stage, host, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -529,18 +557,29 @@ extern "C" int gpf_pre_run(gpf_handle* h) {
 // ---------------------------------------------------------------------------------------------
 typedef void (*step_kernel_t)(const StepArgs, const Phys);
 
-static step_kernel_t step_kernel(int eos, bool has_ls, bool piezo, int D) {
+// topo_mode: 0 planes, 1 profile over ix, 2 profile over iy (only without slip-length field / piezo-viscosity)
+static step_kernel_t step_kernel(int eos, bool has_ls, bool piezo, int D, int topo_mode) {
     step_kernel_t k = nullptr;
     EOS_DISPATCH(eos, {
         if (piezo) {
-            if (has_ls) k = D > 0 ? k_step<EOS_, true, true, 1> : k_step<EOS_, true, true, -1>;
-            else k = D > 0 ? k_step<EOS_, false, true, 1> : k_step<EOS_, false, true, -1>;
+            if (has_ls) k = D > 0 ? k_step<EOS_, true, true, 1, 0> : k_step<EOS_, true, true, -1, 0>;
+            else k = D > 0 ? k_step<EOS_, false, true, 1, 0> : k_step<EOS_, false, true, -1, 0>;
+        } else if (has_ls) {
+            k = D > 0 ? k_step<EOS_, true, false, 1, 0> : k_step<EOS_, true, false, -1, 0>;
+        } else if (topo_mode == 1) {
+            k = D > 0 ? k_step<EOS_, false, false, 1, 1> : k_step<EOS_, false, false, -1, 1>;
+        } else if (topo_mode == 2) {
+            k = D > 0 ? k_step<EOS_, false, false, 1, 2> : k_step<EOS_, false, false, -1, 2>;
         } else {
-            if (has_ls) k = D > 0 ? k_step<EOS_, true, false, 1> : k_step<EOS_, true, false, -1>;
-            else k = D > 0 ? k_step<EOS_, false, false, 1> : k_step<EOS_, false, false, -1>;
+            k = D > 0 ? k_step<EOS_, false, false, 1, 0> : k_step<EOS_, false, false, -1, 0>;
         }
     });
     return k;
+}
+
+static int topo_mode_of(const gpf_handle* h) {
+    if (h->Ls != nullptr || h->cfg.piezo != 0 || std::getenv("GPF_TOPO_PLANES")) return 0;
+    return h->topo_mode;
 }
 
 // One wave marches over `rows_per_chunk` rows of one strip.  The chunks are sized so that the whole
@@ -552,7 +591,7 @@ static int plan_step(gpf_handle* h) {
     if (const char* s = std::getenv("GPF_ROWS_PER_CHUNK")) rows = std::atoi(s);
     if (rows <= 0) {
         int per_cu = 0, ncu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)step_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, 1), 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)step_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, 1, topo_mode_of(h)), 256, 0));
         HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->cfg.device));
         const int blocks_per_chunk = (h->nstrips + 3) / 4;
         const int resident = std::max(1, per_cu * ncu);
@@ -577,7 +616,7 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     h->next_step += 1;
     const int np_step = h->nstrips * h->nchunks;
     StepArgs a;
-    a.qa = h->q[0]; a.qb = h->q[1]; a.topo = h->topo; a.Ls = h->Ls;
+    a.qa = h->q[0]; a.qb = h->q[1]; a.topo = h->topo; a.topo_line = h->topo_line; a.Ls = h->Ls;
     a.g1x = h->g1; a.g1y = h->g1 + 3 * L.pitch;
     a.st = h->st; a.partials = h->partials; a.L = L; a.E = h->E;
     a.rows_per_chunk = h->rows_per_chunk; a.nstrips = h->nstrips; a.honor_stop = honor_stop;
@@ -603,7 +642,7 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
 
     const int gmax = std::max(L.Nx, L.Ny);
     const dim3 ggrid((gmax + 255) / 256, 2), sgrid((h->nstrips + 3) / 4, h->nchunks);
-    const step_kernel_t kstep = step_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, D);
+    const step_kernel_t kstep = step_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, D, topo_mode_of(h));
     const bool slab = slab_out != nullptr;
     const int nprep = (L.Nx + L.Ny + 255) / 256;
     EOS_DISPATCH(h->cfg.eos, {

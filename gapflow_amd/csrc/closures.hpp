@@ -224,6 +224,11 @@ GPF_HD TopoRcp topo_rcp(const CellIn& c) {
 // takes the constant viscosities from Phys (no per-cell exp/pow).
 template <int EOS, bool WITH_SOURCE, bool HAS_LS = true, bool PIEZO = true>
 GPF_HD void cell_closure(const CellIn& c, const TopoRcp& t, const Phys& P, CellFlux& o) {
+#ifdef GPF_STUB_CLOSURE     // diagnostic build: memory-access pattern of the step without its arithmetic
+    o.p = c.rho; o.fx1 = c.rho + c.h; o.fx2 = c.jx + c.hx; o.fy2 = c.jy + c.hy;
+    o.s0 = c.h; o.s1 = c.hx; o.s2 = c.hy;
+    return;
+#endif
     const double U = P.U, V = P.V;
     const double p = eos_pressure<EOS>(c.rho, P);
     const double eta = (!PIEZO || P.piezo == PIEZO_NONE) ? P.eta : piezo_eta(P.eta, (EOS == EOS_BAYADA) ? c.rho : p, P);

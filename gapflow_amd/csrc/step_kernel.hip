@@ -48,6 +48,7 @@ struct StepArgs {
     const double* qa;           // q buffer 0 (3 planes)
     const double* qb;           // q buffer 1
     const double* topo;         // h, hx, hy planes
+    const double* topo_line;    // TOPO = 1: [3][Nx+2] profile over ix; TOPO = 2: [3][Ny+2] profile over iy
     const double* Ls;           // slip-length plane or nullptr
     const double* g1x;          // [3][pitch]  stage-1 field on the downwind physical ghost row
     const double* g1y;          // [3][Nx+2]   ... on the downwind physical ghost column
@@ -76,7 +77,7 @@ __device__ __forceinline__ int direction_of_step(const StepState* st, long long 
 }
 __device__ __forceinline__ int predictor_direction(const StepState* st) { return direction_of_step(st, st->step); }
 
-template <int EOS, bool HAS_LS, bool PIEZO, int D>
+template <int EOS, bool HAS_LS, bool PIEZO, int D, int TOPO>
 __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, const double* __restrict__ qin,
                                            double* __restrict__ qout) {
     const Layout L = a.L;
@@ -109,12 +110,26 @@ __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, con
     double* __restrict__ qo1 = qout + L.plane;
     double* __restrict__ qo2 = qout + 2 * L.plane;
 
+    // TOPO: most gap profiles vary along one axis only (journal, inclined, parabolic, cdc: h = h(x)).  Then a third
+    // of the step's HBM reads is redundant: TOPO = 1 reads one (h, hx, hy) triple per ROW through the scalar cache
+    // (the row index is wave-uniform), TOPO = 2 keeps the lane's column triple in registers for the whole march.
+    // The planes stay resident for every other kernel; the values are bitwise the same.
+    double lh = 0.0, lhx = 0.0, lhy = 0.0;
+    if (TOPO == 2) {
+        lh = a.topo_line[iy]; lhx = a.topo_line[(L.Ny + 2) + iy]; lhy = a.topo_line[2 * (L.Ny + 2) + iy];
+    }
     // per-lane element offsets fit 32 bits (a plane is < 2^28 doubles); the plane bases stay in SGPRs
     auto load = [&](int n, CellIn& c) {
         const int ix = D > 0 ? n : L.Nx + 1 - n;
         const int o = ix * L.pitch + L.off + iy;
         c.rho = q0p[o]; c.jx = q1p[o]; c.jy = q2p[o];
-        c.h = hp[o]; c.hx = hxp[o]; c.hy = hyp[o];
+        if (TOPO == 0) {
+            c.h = hp[o]; c.hx = hxp[o]; c.hy = hyp[o];
+        } else if (TOPO == 1) {
+            c.h = a.topo_line[ix]; c.hx = a.topo_line[(L.Nx + 2) + ix]; c.hy = a.topo_line[2 * (L.Nx + 2) + ix];
+        } else {
+            c.h = lh; c.hx = lhx; c.hy = lhy;
+        }
         c.Ls = HAS_LS ? a.Ls[o] : 0.0;
     };
 
@@ -215,14 +230,14 @@ __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, con
 
 // D = direction of the predictor, chosen by the host from the step index (problem.py:521-522);
 // the device-side step counter is checked against it so a disagreement can never go unnoticed.
-template <int EOS, bool HAS_LS, bool PIEZO, int D>
+template <int EOS, bool HAS_LS, bool PIEZO, int D, int TOPO>
 __global__ __launch_bounds__(256) void k_step(const StepArgs a, const Phys P) {
     if (halted(a.st, a.honor_stop)) return;
     if (predictor_direction(a.st) != D) __builtin_trap();
     const int par = a.st->parity;
     const double* qin = par ? a.qb : a.qa;
     double* qout = const_cast<double*>(par ? a.qa : a.qb);
-    step_strip<EOS, HAS_LS, PIEZO, D>(a, P, qin, qout);
+    step_strip<EOS, HAS_LS, PIEZO, D, TOPO>(a, P, qin, qout);
 }
 
 // ---------------------------------------------------------------------------------------------
