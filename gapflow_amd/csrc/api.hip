@@ -476,7 +476,8 @@ static int launch_scalars(gpf_handle* h, const double* q, ScalarPartial* total, 
 static void fill_scalars(const StepState& s, const ScalarPartial* sp, double dxdy, gpf_scalars_t* out) {
     out->step = s.step; out->simtime = s.simtime; out->dt = s.dt;
     out->ekin = sp ? sp->ekin : s.ekin; out->ekin_old = s.ekin_old; out->residual = s.residual;
-    out->v_max = std::sqrt(sp ? sp->v2 : s.vmax2); out->v_sound = std::sqrt(sp ? sp->c2 : s.c2max);
+    out->v_max = std::sqrt(sp ? sp->v2 : s.vmax2);
+    out->v_sound = (sp && ((int)sp->flags & 4)) ? std::nan("") : std::sqrt(sp ? sp->c2 : s.c2max);
     out->mass = sp ? sp->mass * dxdy : 0.0;
     out->invalid = s.invalid; out->converged = s.converged;
 }

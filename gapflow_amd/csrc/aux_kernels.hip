@@ -87,9 +87,9 @@ struct Acc {
         const double v = (jx * jx + jy * jy) / r;
         ekin += w * (v * 0.5);
         v2 = nanmax(v2, v);
-        double c = eos_c2<EOS>(r, P);
-        c = (c < 0.0) ? __builtin_nan("") : c;
-        c2 = nanmax(c2, c);
+        const double c = eos_c2<EOS>(r, P);
+        if (!(c >= 0.0)) flags |= 4;
+        c2 = fmax(c2, c);
         mass += w * (r * h);
         if (r != r || jx != jx || jy != jy) flags |= 1;
         if (r < 0.0) flags |= 2;
@@ -151,6 +151,8 @@ __global__ __launch_bounds__(256) void k_scalars(const double* q, const double* 
 // ---------------------------------------------------------------------------------------------
 __device__ inline void commit_step(StepState* st, double ekin, double v2, double c2, int flags, LogEntry* log,
                                    long long log_base, long long log_cap) {
+    if (flags & 4) c2 = __builtin_nan("");      // an imaginary sound speed somewhere: np.sqrt -> NaN -> max -> NaN
+    flags &= 3;
     if (flags) {
         // invalid state: keep the pre-step field (parity not flipped) and stop (problem.py:588-610)
         st->invalid = (flags & 1) ? 1 : 2;
@@ -547,7 +549,7 @@ __global__ void k_copy3(const double* src, double* dst, long long n) {
 // commit for the unfused path: validity is judged BEFORE the final ghost update (problem.py:565),
 // scalars after it (problem.py:576-578); both from k_scalars records.
 __global__ void k_commit_unfused(StepState* st, const ScalarPartial* pre_bc, const ScalarPartial* post_bc) {
-    int flags = (int)pre_bc->flags;
+    const int flags = ((int)pre_bc->flags & 3) | ((int)post_bc->flags & 4);
     commit_step(st, post_bc->ekin, post_bc->v2, post_bc->c2, flags, nullptr, 0, 0);
 }
 

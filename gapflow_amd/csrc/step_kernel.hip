@@ -133,18 +133,21 @@ __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, con
         c.Ls = HAS_LS ? a.Ls[o] : 0.0;
     };
 
-    CellIn cur, nxt;
+    // rows n+1 and n+2 are in flight while row n is computed (with a line topography a row is only three
+    // loads per lane, and one row ahead leaves too few bytes in flight to cover the HBM latency)
+    CellIn cur, nxt, nxt2;
     load(n_first - 1, cur);
+    load(n_first, nxt);
 
     // carried from the previous row
     double fx1p0 = 0, fx1p1 = 0, fx1p2 = 0;     // stage-1 x-flux of row n-1
     double part0 = 0, part1 = 0, part2 = 0;     // row n-1: q(t0) + q1 - dt*(-cx*Fx2 + cy*dFy2 - S2)
     // reductions over this wave's output cells
-    double r_ekin = 0.0, r_v2 = 0.0, r_c2 = 0.0;
+    double r_ekin = 0.0, r_v2 = 0.0, r_c2 = (EOS == EOS_DH) ? __builtin_inf() : 0.0;
     int r_flags = 0;
 
     for (int n = n_first - 1; n <= n_last + 1; ++n) {
-        if (n <= n_last) load(n + 1, nxt);                  // one row ahead
+        if (n < n_last) load(n + 2, nxt2);
         const bool first = (n == n_first - 1);
         const bool last = (n == n_last + 1);
         const int ix = D > 0 ? n : L.Nx + 1 - n;
@@ -198,12 +201,22 @@ __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, con
                     const double w = 1.0 + ((ixo == 1 && a.E.halo[0] == 2) ? 1.0 : 0.0) +
                                      ((ixo == L.Nx && a.E.halo[1] == 2) ? 1.0 : 0.0);
                     r_ekin += w * (v2 * 0.5);
-                    r_v2 = nanmax(r_v2, v2);
-                    double c2 = eos_c2<EOS>(o0, P);
-                    c2 = (c2 < 0.0) ? __builtin_nan("") : c2;
-                    r_c2 = nanmax(r_c2, c2);
-                    if (o0 != o0 || o1 != o1 || o2 != o2) r_flags |= 1;
+                    // Flags instead of NaN-propagating maxima in the hot loop: a NaN in any component makes v2 NaN
+                    // (flag 1: the state is invalid and the step is undone, problem.py:319-332, so the maxima are
+                    // then irrelevant); an imaginary sound speed raises flag 4 and k_finish turns c2max into NaN,
+                    // which is what np.sqrt(...).max() yields in the reference (stress.py:539).
+                    r_v2 = fmax(r_v2, v2);
+                    if (v2 != v2) r_flags |= 1;
                     if (o0 < 0.0) r_flags |= 2;
+                    if (EOS == EOS_DH) {
+                        // dp/drho = K / (C2 rho0 - rho)^2 grows monotonically towards the pole: its maximum sits at
+                        // the cell closest to it, so one reciprocal per WAVE (below) replaces one per cell
+                        r_c2 = fmin(r_c2, fabs(P.e[7] - o0));
+                    } else {
+                        const double c2 = eos_c2<EOS>(o0, P);
+                        if (!(c2 >= 0.0)) r_flags |= 4;
+                        r_c2 = fmax(r_c2, c2);
+                    }
                 }
             }
             // ---- open row n (an output row unless this is the downwind extra row) ----
@@ -212,16 +225,22 @@ __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, con
             part2 = (cur.jy + q12) - dt * (-cx * g.fx2 + cy * (d2 - gy2) - g.s2);
         }
         cur = nxt;
+        nxt = nxt2;
     }
 
     // ---- wave reduction, one record per wave ----
     for (int s = 32; s >= 1; s >>= 1) {
         r_ekin += __shfl_down(r_ekin, s);
-        r_v2 = nanmax(r_v2, __shfl_down(r_v2, s));
-        r_c2 = nanmax(r_c2, __shfl_down(r_c2, s));
+        r_v2 = fmax(r_v2, __shfl_down(r_v2, s));
+        const double oc = __shfl_down(r_c2, s);
+        r_c2 = (EOS == EOS_DH) ? fmin(r_c2, oc) : fmax(r_c2, oc);
         r_flags |= __shfl_down(r_flags, s);
     }
     if (lane == 0) {
+        if (EOS == EOS_DH) {                    // same expression as eos_c2<EOS_DH> at the cell nearest the pole
+            const double it = rcp(r_c2);
+            r_c2 = (r_c2 == __builtin_inf()) ? 0.0 : P.e[6] * (it * it);
+        }
         Partial p;
         p.ekin = r_ekin; p.vmax2 = r_v2; p.c2max = r_c2; p.flags = (double)r_flags;
         a.partials[(long long)chunk * a.nstrips + strip] = p;
