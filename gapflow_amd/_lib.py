@@ -68,6 +68,10 @@ SIGNATURES = {
     'gpf_step_local': (C.c_int, [C.c_void_p, C.c_int]),
     'gpf_step_commit': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     'gpf_state': (C.c_int, [C.c_void_p, C.POINTER(GpfScalars)]),
+    'gpf_stage_message': (C.c_int, [C.c_void_p]),
+    'gpf_stage_absorb': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    'gpf_close_step_local': (C.c_int, [C.c_void_p]),
+    'gpf_close_step_commit': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(GpfScalars)]),
     'gpf_set_seam_topo': (C.c_int, [C.c_void_p, C.c_int, _DP, C.c_size_t]),
     'gpf_predictor_corrector': (C.c_int, [C.c_int, C.c_int, _DP, _DP, _DP, C.c_int, _DP, _DP]),
     'gpf_source': (C.c_int, [C.c_int, C.c_int, _DP, _DP, _DP, _DP, _DP, _DP]),

@@ -459,7 +459,8 @@ extern "C" int gpf_update_closures(gpf_handle* h) {
 // ---------------------------------------------------------------------------------------------
 static int launch_scalars(gpf_handle* h, const double* q, ScalarPartial* total, bool need_sound_speed = true) {
     const Layout& L = h->L;
-    const int row0 = h->E.halo[0] ? 1 : 0, row1 = h->E.halo[1] ? L.Nx : L.Nx + 1;
+    // a slab leaves out copies of its neighbours' rows (kind 1); the domain's own ghost rows (kinds 0, 2) count
+    const int row0 = h->E.halo[0] == 1 ? 1 : 0, row1 = h->E.halo[1] == 1 ? L.Nx : L.Nx + 1;
     const long long n = (long long)(row1 - row0 + 1) * (L.Ny + 2);
     const int nb = blocks_for(n, 256, h->nspart);
     EOS_DISPATCH(h->cfg.eos, {
@@ -842,6 +843,7 @@ static HaloArgs halo_args(gpf_handle* h, int honor_stop, const double* gathered,
     a.qa = h->q[0]; a.qb = h->q[1];
     a.msg = h->halo; a.gathered = gathered; a.rank_lo = rank_lo; a.rank_hi = rank_hi;
     a.st = h->st; a.L = h->L; a.E = h->E; a.honor_stop = honor_stop;
+    a.work_parity = -1;
     return a;
 }
 
@@ -1232,6 +1234,69 @@ extern "C" int gpf_close_step(gpf_handle* h, gpf_scalars_t* out) {
     hipLaunchKernelGGL(k_bc_y, dim3((L.Nx + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
     GPF_TRY(launch_scalars(h, q, post));                // scalars after the ghost update (problem.py:576-578)
     hipLaunchKernelGGL(k_commit_unfused, dim3(1), dim3(1), 0, h->stream, h->st, pre, post);
+    HIP_TRY(hipGetLastError());
+    h->step_open = false;
+    StepState s;
+    GPF_TRY(read_state(h, s));
+    h->host_step = s.step; h->next_step = s.step;
+    if (out) fill_scalars(s, nullptr, 0.0, out);
+    return GPF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage-wise step of a slab (GP closures / shear thinning across several GPUs): the rows a neighbour needs
+// travel after EACH stage, the scalars once per step
+// ---------------------------------------------------------------------------------------------
+extern "C" int gpf_stage_message(gpf_handle* h) {
+    if (!h || !h->step_open) return fail(GPF_ERR_STATE, "gpf_stage_message: no open step");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    GPF_TRY(ensure_halo(h));
+    HaloArgs a = halo_args(h, 0, nullptr, -1, -1);
+    a.work_parity = h->open_parity ^ 1;
+    hipLaunchKernelGGL(k_halo_pack, dim3((h->L.pitch + 255) / 256), dim3(256), 0, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    return GPF_OK;
+}
+
+extern "C" int gpf_stage_absorb(gpf_handle* h, const void* gathered, int nranks, int rank_lo, int rank_hi) {
+    if (!h || !gathered || nranks < 1) return fail(GPF_ERR_INVALID, "gpf_stage_absorb: bad argument");
+    if (!h->step_open) return fail(GPF_ERR_STATE, "gpf_stage_absorb: no open step");
+    if (rank_lo >= nranks || rank_hi >= nranks) return fail(GPF_ERR_INVALID, "gpf_stage_absorb: neighbour rank out of range");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HaloArgs a = halo_args(h, 0, (const double*)gathered, rank_lo, rank_hi);
+    a.work_parity = h->open_parity ^ 1;
+    hipLaunchKernelGGL(k_halo_unpack, dim3((h->L.pitch + 255) / 256), dim3(256), 0, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    return GPF_OK;
+}
+
+// average + validity + ghost rules + this slab's share of the scalars -> record in the message
+extern "C" int gpf_close_step_local(gpf_handle* h) {
+    if (!h || !h->step_open) return fail(GPF_ERR_STATE, "gpf_close_step_local: no open step");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    GPF_TRY(ensure_halo(h));
+    const Layout& L = h->L;
+    double* q = h->q[h->open_parity ^ 1];
+    const double* q0 = h->q[h->open_parity];
+    const long long n = (long long)(L.Nx + 2) * (L.Ny + 2);
+    hipLaunchKernelGGL(k_average, dim3(blocks_for(n)), dim3(256), 0, h->stream, q, q0, L);
+    ScalarPartial* pre = h->spart + h->nspart;
+    ScalarPartial* post = h->spart + h->nspart + 1;
+    GPF_TRY(launch_scalars(h, q, pre, false));
+    hipLaunchKernelGGL(k_bc_x, dim3((L.Ny + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
+    hipLaunchKernelGGL(k_bc_y, dim3((L.Nx + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
+    GPF_TRY(launch_scalars(h, q, post));
+    hipLaunchKernelGGL(k_record_unfused, dim3(1), dim3(1), 0, h->stream, pre, post, h->halo + (size_t)6 * L.pitch);
+    HIP_TRY(hipGetLastError());
+    return GPF_OK;
+}
+
+extern "C" int gpf_close_step_commit(gpf_handle* h, const void* gathered, int nranks, gpf_scalars_t* out) {
+    if (!h || !gathered || nranks < 1) return fail(GPF_ERR_INVALID, "gpf_close_step_commit: bad argument");
+    if (!h->step_open) return fail(GPF_ERR_STATE, "gpf_close_step_commit: no open step");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_commit_gathered, dim3(1), dim3(1), 0, h->stream, h->st, (const double*)gathered,
+                       (long long)halo_len(h), (long long)6 * h->L.pitch, nranks, (LogEntry*)nullptr, 0ll, 0ll, 0);
     HIP_TRY(hipGetLastError());
     h->step_open = false;
     StepState s;

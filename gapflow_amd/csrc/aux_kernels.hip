@@ -362,10 +362,11 @@ struct HaloArgs {
     const StepState* st;
     Layout L; Edges E;
     int honor_stop;
+    int work_parity;            // -1: the buffer the fused step wrote (!parity); 0/1: that buffer (stage-wise step)
 };
 __global__ void k_halo_pack(const HaloArgs a) {
     if (a.st->invalid != 0 || (a.honor_stop && (a.st->converged || a.st->step >= a.st->max_it))) return;
-    const double* q = a.st->parity ? a.qa : a.qb;
+    const double* q = a.work_parity >= 0 ? (a.work_parity ? a.qb : a.qa) : (a.st->parity ? a.qa : a.qb);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.L.pitch) return;
     for (int c = 0; c < 3; ++c) {
@@ -375,7 +376,7 @@ __global__ void k_halo_pack(const HaloArgs a) {
 }
 __global__ void k_halo_unpack(const HaloArgs a) {
     if (a.st->invalid != 0 || (a.honor_stop && (a.st->converged || a.st->step >= a.st->max_it))) return;
-    double* q = a.st->parity ? a.qa : a.qb;
+    double* q = a.work_parity >= 0 ? (a.work_parity ? a.qb : a.qa) : (a.st->parity ? a.qa : a.qb);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.L.pitch) return;
     const long long len = 6ll * a.L.pitch + 8;
@@ -384,6 +385,16 @@ __global__ void k_halo_unpack(const HaloArgs a) {
         if (a.E.halo[1] && a.rank_hi >= 0)
             q[c * a.L.plane + (long long)(a.L.Nx + 1) * a.L.pitch + i] = a.gathered[a.rank_hi * len + c * a.L.pitch + i];
     }
+}
+
+// stage-wise slab step: validity from the pre-ghost-update scalars, values from the post-update ones (problem.py:565-578)
+__global__ void k_record_unfused(const ScalarPartial* pre, const ScalarPartial* post, double* rec) {
+    const double inf = __builtin_inf();
+    rec[0] = post->ekin;
+    rec[1] = post->v2 != post->v2 ? inf : post->v2;
+    rec[2] = post->c2 != post->c2 ? inf : post->c2;
+    rec[3] = (double)(((int)pre->flags & 3) | ((int)post->flags & 4));
+    rec[4] = rec[5] = rec[6] = rec[7] = 0.0;
 }
 
 // slab mode: reduce the gathered per-slab records in rank order (identical on every rank), then commit

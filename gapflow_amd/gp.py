@@ -17,7 +17,9 @@ in dtool datasets and the LAMMPS runners are out of scope; the database lives in
 Deliberate deviation: jax's PRNG streams (db.py:326-336, mock.py:82-88) cannot be reproduced without jax;
 NumPy's default_rng with the same seeds is used instead.
 """
+import contextlib
 import ctypes as C
+import io as _io
 from datetime import datetime
 
 import numpy as np
@@ -66,7 +68,8 @@ class Mock:
     name = 'mock'
     is_mock = True
 
-    def __init__(self, prop, geo, gp):
+    def __init__(self, prop, geo, gp, device=0):
+        self.device = device
         self.noise = (gp['press']['obs_stddev'] if gp['press_gp'] else 0.,
                       gp['shear']['obs_stddev'] if gp['shear_gp'] else 0.)
         self.prop, self.geo = prop, geo
@@ -84,7 +87,7 @@ class Mock:
             prop = {k: v for k, v in self.prop.items() if k not in ('piezo', 'thinning')}
             prop.setdefault('elastic', {'enabled': False})
             self._eval = Problem({'output': '', 'write_freq': 1, 'use_tstamp': False, 'silent': True}, grid, numerics,
-                                 prop, geo)
+                                 prop, geo, device=self.device)
         return self._eval
 
     def run(self, X, tag=None):
@@ -178,14 +181,14 @@ class Database:
             self._X_scale, self._Y_scale = self._normalizer(self._Xtrain), self._normalizer(self._Ytrain)
 
 
-def make_database(input_dict):
+def make_database(input_dict, device=0):
     """problem.py:223-249: a `db` section without `md` attaches the Mock runner."""
     if input_dict.get('md') is not None:
         raise NotImplementedError("LAMMPS MD runners (GaPFlow/md/) are outside the scope of the MI355X hot path")
     gp = input_dict.get('gp')
     if gp is None:
         raise IOError("a `db` section needs a `gp` section")
-    return Database(Mock(input_dict['properties'], input_dict['geometry'], gp), input_dict['db'])
+    return Database(Mock(input_dict['properties'], input_dict['geometry'], gp, device), input_dict['db'])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -326,6 +329,10 @@ class Surrogate:
             mean = np.stack([p._derived(_lib.FIELD_WALL_LOWER)[oi], p._derived(_lib.FIELD_WALL_UPPER)[oi]])
         return mean, self.variance
 
+    def _most_uncertain(self, features_of_cell):
+        """Features of the cell with the largest predictive variance (gp.py:428-430)."""
+        return features_of_cell(int(np.argmax(self.variance)))
+
     def stage(self, predictor, compute_var, features_of_cell):
         """The host side of predict() for one stage of an open step (gp.py:435-506).
         Returns True if the device model changed (the caller re-evaluates the stage's closures)."""
@@ -346,8 +353,7 @@ class Surrogate:
             before = self.maximum_variance / self.variance_tol
             while not self.trusted and counter < self.max_steps:
                 counter += 1
-                imax = int(np.argmax(self.variance))                      # gp.py:428-430
-                self.database.add_data(features_of_cell(imax)[None, :])
+                self.database.add_data(self._most_uncertain(features_of_cell)[None, :])
                 tic = datetime.now()
                 self.train(reason=1)
                 self.cumtime_train += datetime.now() - tic
@@ -364,13 +370,35 @@ class Surrogate:
         return changed
 
 
-def attach_surrogates(problem, gp, database):
+def attach_surrogates(problem, gp, database, cls=Surrogate):
     """Problem._select_gp_config (problem.py:643-660): press + shear-x in 1-D, + shear-y in 2-D."""
     models = {}
     if gp.get('press') is not None:
-        models['zz'] = Surrogate(problem, 'zz', gp['press'], database)
+        models['zz'] = cls(problem, 'zz', gp['press'], database)
     if gp.get('shear') is not None:
-        models['xz'] = Surrogate(problem, 'xz', gp['shear'], database)
+        models['xz'] = cls(problem, 'xz', gp['shear'], database)
         if problem.grid['dim'] == 2:
-            models['yz'] = Surrogate(problem, 'yz', gp['shear'], database)
+            models['yz'] = cls(problem, 'yz', gp['shear'], database)
     return models
+
+
+class SlabSurrogate(Surrogate):
+    """A surrogate of a slab-decomposed problem.  Database, hyper-parameters and factorisation are replicated on
+    every rank (same data, same deterministic host optimiser); only the two domain-wide decisions of active
+    learning -- the largest variance and the cell it belongs to -- are exchanged."""
+
+    def train(self, reason=0, optimise=None):
+        if self._p.rank == 0:
+            return super().train(reason, optimise)
+        with contextlib.redirect_stdout(_io.StringIO()):        # one training report per job, not per rank
+            return super().train(reason, optimise)
+
+    def compute_variance(self, on_open_step):
+        super().compute_variance(on_open_step)
+        self._local_maximum = self.maximum_variance
+        self.maximum_variance = self._p.domain_max(self.maximum_variance)
+
+    def _most_uncertain(self, features_of_cell):
+        var = self.variance
+        i = int(np.argmax(var))
+        return self._p.features_of_domain_max(float(var.flat[i]), features_of_cell(i))

@@ -190,8 +190,6 @@ class SlabProblem:
         import torch
         if dist is None:
             import torch.distributed as dist
-        if input_dict.get('gp') is not None or input_dict.get('db') is not None:
-            raise NotImplementedError("GP closures are not available in slab mode yet")
         self.torch, self.dist = torch, dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.input = input_dict
@@ -205,6 +203,9 @@ class SlabProblem:
         shell.options, shell.numerics, shell.prop, shell.geo = input_dict['options'], input_dict['numerics'], prop, geo
         shell.grid = L.local_grid(grid)
         cfg = shell._make_config(device)
+        if cfg.thinning:
+            # the viscosity of a halo row depends on grad p there, i.e. on a second row of the neighbour
+            raise NotImplementedError("shear thinning needs a two-row halo; not available in slab mode")
         cfg.halo_lo, cfg.halo_hi = L.kind_lo, L.kind_hi
         self.grid_local = shell.grid
         self._h = C.c_void_p()
@@ -229,6 +230,25 @@ class SlabProblem:
                 _lib.check(self.lib.gpf_set_seam_topo(self._h, side, _lib.as_dp(seam), seam.size))
         self.engine = HipSlabEngine(self.lib, self._h, torch, self.world)
         self.driver = SlabDriver(self.engine, L, dist, torch)
+
+        # surrogate closures: the database and the models are replicated on every rank
+        self.grid, self._lib, self._closures_stale = grid, self.lib, True
+        self._topo_local = topo[:3, rows].copy()
+        self._extra = np.zeros((1,) + shape)
+        self._features_global = np.vstack([np.broadcast_to(q[:, :1, :1], (3,) + topo.shape[1:]), topo[:3],
+                                           np.zeros((1,) + topo.shape[1:])]).reshape(7, -1).T
+        self.database, self._gp_models = None, {}
+        gp = input_dict.get('gp')
+        if input_dict.get('db') is not None:
+            from .gp import make_database
+            self.database = make_database(input_dict, device)
+        if gp is not None:
+            if self.database is None:
+                raise IOError("a `gp` section needs a `db` section")
+            from .gp import attach_surrogates, SlabSurrogate
+            self._gp_models = attach_surrogates(self, gp, self.database, cls=SlabSurrogate)
+            self._pair = torch.zeros(8, dtype=torch.float64, device='cuda')
+            self._pairs = torch.zeros(8 * self.world, dtype=torch.float64, device='cuda')
 
     def __del__(self):
         h = getattr(self, '_h', None)
@@ -261,8 +281,39 @@ class SlabProblem:
         self.dist.all_reduce(m, op=self.dist.ReduceOp.MAX)
         return {'ekin': float(s[0]), 'mass': float(s[1]), 'v_max': float(m[0]), 'v_sound': float(m[1])}
 
+    # -- what a SlabSurrogate asks of its problem -----------------------------------------------
+    def _download(self, field, ncomp):
+        out = np.empty((ncomp,) + self._shape)
+        _lib.check(self.lib.gpf_download(self._h, field, _lib.as_dp(out), out.size))
+        return out
+
+    def _sync_to_device(self):
+        pass
+
+    def _gather_pairs(self, value, payload):
+        t = self.torch
+        self._pair.copy_(t.tensor([value] + list(payload), dtype=t.float64))
+        self.dist.all_gather_into_tensor(self._pairs, self._pair)
+        return self._pairs.cpu().numpy().reshape(self.world, 8)
+
+    def domain_max(self, value):
+        return float(np.max(self._gather_pairs(value, np.zeros(7))[:, 0]))
+
+    def features_of_domain_max(self, value, features):
+        """Feature row of the most uncertain cell of the whole domain: the lowest rank holding the maximum wins,
+        like the first hit of the serial argmax (rows shared by two slabs carry identical features)."""
+        pairs = self._gather_pairs(value, features)
+        return pairs[int(np.argmax(pairs[:, 0])), 1:].copy()
+
+    def _features_local(self):
+        return np.vstack([self.local_q(), self._topo_local, self._extra]).reshape(7, -1).T
+
     def pre_run(self):
         """Problem._pre_run (problem.py:412-443) with domain-wide scalars."""
+        if self._gp_models:
+            self.database.initialize(self._features_global, self.grid['dim'])       # identical on every rank
+            for m in self._gp_models.values():
+                m.train(reason=0)
         _lib.check(self.lib.gpf_pre_run(self._h))
         g = self.global_scalars()
         num, grid = self.input['numerics'], self.input['grid']
@@ -271,8 +322,48 @@ class SlabProblem:
         _lib.check(self.lib.gpf_set_dt(self._h, float(dt)))
         _lib.check(self.lib.gpf_set_ekin_old(self._h, float(g['ekin'])))
 
-    def advance(self, n, honor_stop=False):
-        self.driver.advance(n, honor_stop)
+    def advance(self, n, honor_stop=False, write_freq=None):
+        if not self._gp_models:
+            return self.driver.advance(n, honor_stop)
+        for _ in range(n):
+            st = self.state()
+            if st.invalid or (honor_stop and (st.converged or st.step >= self.input['numerics']['max_it'])):
+                break
+            self._stagewise_step(write_freq or self.input['options']['write_freq'], st.step)
+
+    def _stagewise_step(self, write_freq, step):
+        """Problem._update_with_surrogates for a slab: the working field's outer rows travel after each stage
+        (the closures of the next stage read them), the scalar records once at the end."""
+        lib, h, d = self.lib, self._h, self.driver
+        gathered = C.c_void_p(d.gathered.data_ptr())
+        one_step_before_output = (step + 1) % write_freq == 0
+        feats = None
+
+        def features_of_cell(i):
+            nonlocal feats
+            if feats is None:
+                feats = self._features_local()
+            return feats[i]
+
+        _lib.check(lib.gpf_open_step(h))
+        for i in range(2):
+            _lib.check(lib.gpf_stage_closures(h))
+            changed = False
+            for name in ('zz', 'xz', 'yz'):
+                m = self._gp_models.get(name)
+                if m is not None:
+                    changed |= m.stage(i == 0, one_step_before_output, features_of_cell)
+            if changed:
+                _lib.check(lib.gpf_stage_closures(h))
+            _lib.check(lib.gpf_stage_advance(h, i))
+            _lib.check(lib.gpf_stage_message(h))
+            self.dist.all_gather_into_tensor(d.gathered, d.message)
+            _lib.check(lib.gpf_stage_absorb(h, gathered, self.world, d.rank_lo, d.rank_hi))
+        _lib.check(lib.gpf_close_step_local(h))
+        self.dist.all_gather_into_tensor(d.gathered, d.message)
+        sc = _lib.GpfScalars()
+        _lib.check(lib.gpf_close_step_commit(h, gathered, self.world, C.byref(sc)))
+        return sc
 
     def state(self):
         sc = _lib.GpfScalars()

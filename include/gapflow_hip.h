@@ -166,6 +166,14 @@ int gpf_set_dt(gpf_handle* h, double dt);
 int gpf_slab_message(gpf_handle* h, void** message, size_t* count);
 int gpf_step_local(gpf_handle* h, int honor_stop);
 int gpf_step_commit(gpf_handle* h, int honor_stop, const void* gathered, int nranks, int rank_lo, int rank_hi);
+/* Stage-wise step of a slab (GP closures, shear thinning): after each gpf_stage_advance the rows a neighbour needs
+ * are packed from the working field (gpf_stage_message -> the same message buffer), all-gathered by the caller and
+ * scattered (gpf_stage_absorb); gpf_close_step_local averages, applies the local ghost rules and leaves this slab's
+ * record in the message, gpf_close_step_commit reduces the gathered records and advances dt / residual / step. */
+int gpf_stage_message(gpf_handle* h);
+int gpf_stage_absorb(gpf_handle* h, const void* gathered, int nranks, int rank_lo, int rank_hi);
+int gpf_close_step_local(gpf_handle* h);
+int gpf_close_step_commit(gpf_handle* h, const void* gathered, int nranks, gpf_scalars_t* out);
 /* Read back the run state after a batch of split steps (synchronises). */
 int gpf_state(gpf_handle* h, gpf_scalars_t* out);
 /* Topography across a periodic seam (halo kind 2): the rows the far side's first interior cell and

@@ -92,7 +92,8 @@ def _slab_worker(rank, world, port, text, nsteps, out_dir):
         slab.advance(nsteps)
         st = slab.state()
         np.savez(os.path.join(out_dir, f'rank{rank}.npz'), q=slab.local_q(), lo=slab.layout.lo, hi=slab.layout.hi,
-                 dt=st.dt, residual=st.residual, step=st.step, ekin=st.ekin, invalid=st.invalid)
+                 dt=st.dt, residual=st.residual, step=st.step, ekin=st.ekin, invalid=st.invalid,
+                 db_size=0 if slab.database is None else slab.database.size)
     finally:
         dist.destroy_process_group()
 
@@ -133,3 +134,52 @@ def test_multi_rank_engine_matches_serial(hiplib, tmp_path, text, world):
         np.testing.assert_allclose(z['dt'], serial.dt, rtol=1e-12)
         np.testing.assert_allclose(z['ekin'], serial.kinetic_energy, rtol=1e-12)
         np.testing.assert_allclose(z['residual'], serial.residual, rtol=1e-6, atol=1e-10)
+
+
+GP_SIM = """
+options: {silent: True, write_freq: 1000}
+grid: {Nx: 41, Ny: 24, Lx: 0.05, Ly: 0.03, xE: ['D', 'N', 'N'], xW: ['D', 'N', 'N'], xE_D: 877.7007, xW_D: 877.7007,
+       yS: ['P', 'P', 'P'], yN: ['P', 'P', 'P']}
+geometry: {type: inclined, hmax: 6.6e-5, hmin: 2.e-5, U: 20., V: 3.}
+numerics: {CFL: 0.3, adaptive: 1, tol: 1.e-10, max_it: 100}
+properties: {EOS: DH, shear: 0.0794, bulk: 0., rho0: 877.7007, C1: 3.5e9}
+gp:
+    press: {atol: 1., rtol: 0.1, obs_stddev: 1.e5, active_learning: AL_PRESS, max_steps: 3, pause_steps: 4}
+    shear: {atol: 1., rtol: 0.1, obs_stddev: 500., active_learning: False}
+db: {init_size: 24, init_method: lhc, init_width: 0.001}
+"""
+
+GP_PERIODIC = GP_SIM.replace("xE: ['D', 'N', 'N'], xW: ['D', 'N', 'N'], xE_D: 877.7007, xW_D: 877.7007",
+                             "xE: ['P', 'P', 'P'], xW: ['P', 'P', 'P']").replace(
+    'type: inclined, hmax: 6.6e-5, hmin: 2.e-5', 'type: journal, CR: 1.e-2, eps: 0.6')
+
+
+@pytest.mark.parametrize('text,world', [(GP_SIM.replace('AL_PRESS', 'False'), 2), (GP_SIM.replace('AL_PRESS', 'True'), 3),
+                                        (GP_PERIODIC.replace('AL_PRESS', 'False'), 2)])
+def test_multi_rank_gp_closures_match_serial(hiplib, tmp_path, text, world):
+    """Surrogate closures across slabs (stage-wise step, rows exchanged after each stage, replicated database,
+    domain-wide active learning) against the one-handle Problem.update() on the same input."""
+    import torch.multiprocessing as mp
+    from gapflow_amd import Problem
+    nsteps = 6
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_slab_worker, args=(world, port, text, nsteps, str(tmp_path)), nprocs=world, join=True)
+    serial = Problem.from_string(text)
+    serial._pre_run()
+    for _ in range(nsteps):
+        serial.update()
+    ref = serial.q
+    for r in range(world):
+        z = np.load(tmp_path / f'rank{r}.npz')
+        lo, hi = int(z['lo']), int(z['hi'])
+        assert int(z['step']) == nsteps and int(z['invalid']) == 0
+        assert int(z['db_size']) == serial.database.size
+        for c in range(3):
+            scale = np.abs(ref[c]).max() or 1.
+            assert np.abs(z['q'][c] - ref[c, lo - 1:hi + 2]).max() <= 1e-10 * scale, f'rank {r} comp {c}'
+        np.testing.assert_allclose(z['dt'], serial.dt, rtol=1e-10)
+        np.testing.assert_allclose(z['ekin'], serial.kinetic_energy, rtol=1e-10)
+        np.testing.assert_allclose(z['residual'], serial.residual, rtol=1e-5, atol=1e-10)
