@@ -68,6 +68,9 @@ SIGNATURES = {
     'gpf_step_local': (C.c_int, [C.c_void_p, C.c_int]),
     'gpf_step_commit': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     'gpf_state': (C.c_int, [C.c_void_p, C.POINTER(GpfScalars)]),
+    'gpf_p2p_export': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    'gpf_p2p_connect': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
+    'gpf_step_p2p': (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
     'gpf_stage_message': (C.c_int, [C.c_void_p]),
     'gpf_stage_absorb': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     'gpf_close_step_local': (C.c_int, [C.c_void_p]),

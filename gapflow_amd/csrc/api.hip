@@ -51,13 +51,17 @@ struct gpf_handle {
     double* topo_line = nullptr;            // [3][max(Nx,Ny)+2]: the profile when the topography varies along one axis only
     int topo_mode = 0;                      // 0: 2-D planes, 1: function of ix only, 2: function of iy only
     double* Ls = nullptr;                   // 1 plane (allocated on first non-zero upload)
-    double* g1 = nullptr;                   // g1x [3][pitch], g1y [3][Nx+2] finished stage-1 ghost values; then arx [6][pitch], ary [6][Nx+2]
-    bool prepass_valid = false;             // g1 already holds the data of the next step (written by k_edge)
+    double* g1 = nullptr;                   // g1x [3][pitch], g1y [3][Nx+2]: stage-1 ghost values of the step about to run
     double* seam = nullptr;                 // [2 edges][2 rows][4: h,hx,hy,Ls][pitch]
     bool has_seam[2] = {false, false};
+    // peer-to-peer slab transport (gpf_p2p_*): my mailbox, every rank's mailbox as mapped here, message counter
+    struct { bool on = false; int nranks = 0, rank = 0, rank_lo = -1, rank_hi = -1; char* mine = nullptr;
+             char* box[P2P_MAX_RANKS] = {}; unsigned long long* seq = nullptr; } p2p;
     double* halo = nullptr;                 // this slab's all-gather message: first row, last row (3 x pitch each), 8-double record
     StepState* st = nullptr;
     Partial* partials = nullptr;
+    unsigned int* arrive = nullptr;         // blocks of k_ghost_fill that are done (finish_step)
+    Partial* block_partials = nullptr;      // one record per edge-kernel block
     int npartials = 0, nstrips = 0, nchunks = 0, rows_per_chunk = 0, nghost_blocks = 0;
     ScalarPartial* spart = nullptr;         // k_scalars block records (+ 4 totals at the end)
     int nspart = 0;
@@ -251,7 +255,7 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
     }
     HIP_TRY_C(hipMalloc(&h->topo, 3 * plane_b));
     HIP_TRY_C(hipMemset(h->topo, 0, 3 * plane_b));
-    const size_t g1n = (size_t)9 * L.pitch + (size_t)9 * (L.Nx + 2);
+    const size_t g1n = (size_t)3 * L.pitch + (size_t)3 * (L.Nx + 2);
     HIP_TRY_C(hipMalloc(&h->g1, g1n * sizeof(double)));
     HIP_TRY_C(hipMemset(h->g1, 0, g1n * sizeof(double)));
     HIP_TRY_C(hipMalloc(&h->st, sizeof(StepState)));
@@ -259,6 +263,9 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
     h->nghost_blocks = std::max(1, std::min(64, (2 * (L.Ny + 2) + 2 * L.Nx + 255) / 256));
     HIP_TRY_C(hipMalloc(&h->partials, (size_t)(h->npartials + h->nghost_blocks) * sizeof(Partial)));
     HIP_TRY_C(hipMemset(h->partials, 0, (size_t)(h->npartials + h->nghost_blocks) * sizeof(Partial)));
+    HIP_TRY_C(hipMalloc(&h->arrive, sizeof(unsigned int)));
+    HIP_TRY_C(hipMemset(h->arrive, 0, sizeof(unsigned int)));
+    HIP_TRY_C(hipMalloc(&h->block_partials, 1024 * sizeof(Partial)));
     h->nspart = 1024;
     HIP_TRY_C(hipMalloc(&h->spart, (size_t)(h->nspart + 8) * sizeof(ScalarPartial)));
     HIP_TRY_C(hipMemset(h->spart, 0, (size_t)(h->nspart + 8) * sizeof(ScalarPartial)));
@@ -272,11 +279,15 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
 extern "C" int gpf_destroy(gpf_handle* h) {
     if (!h) return GPF_OK;
     hipSetDevice(h->cfg.device);
-    void* ptrs[] = {h->q[0], h->q[1], h->topo, h->topo_line, h->Ls, h->g1, h->seam, h->halo, h->st, h->partials, h->spart,
+    void* ptrs[] = {h->q[0], h->q[1], h->topo, h->topo_line, h->Ls, h->g1, h->seam, h->halo, h->st, h->partials, h->arrive, h->block_partials, h->spart,
                     h->log, h->stage, h->fields, h->work, h->gpvar, h->gpscratch, h->gptile,
                     h->gp[0].Z, h->gp[0].alpha, h->gp[0].L, h->gp[1].Z, h->gp[1].alpha, h->gp[1].L,
                     h->gp[2].Z, h->gp[2].alpha, h->gp[2].L};
     if (h->blas && roclibs().ok) roclibs().destroy(h->blas);
+    for (int r = 0; r < h->p2p.nranks; ++r)
+        if (h->p2p.box[r] && r != h->p2p.rank) hipIpcCloseMemHandle(h->p2p.box[r]);
+    if (h->p2p.mine) hipFree(h->p2p.mine);
+    if (h->p2p.seq) hipFree(h->p2p.seq);
     for (void* p : ptrs)
         if (p) hipFree(p);
     delete h;
@@ -376,7 +387,6 @@ extern "C" int gpf_upload(gpf_handle* h, int field, const double* host, size_t c
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (field == GPF_FIELD_Q) h->has_q = true;
     if (field == GPF_FIELD_TOPO) h->has_topo = true;
-    h->prepass_valid = false;
     return GPF_OK;
 }
 
@@ -549,7 +559,6 @@ extern "C" int gpf_pre_run(gpf_handle* h) {
     s.dt = c.adaptive ? c.CFL * dt_crit : c.dt_fixed;
     GPF_TRY(write_state(h, s));
     h->pre_run_done = true;
-    h->prepass_valid = false;
     h->host_step = 0; h->next_step = 0;
     return GPF_OK;
 }
@@ -609,8 +618,16 @@ static int plan_step(gpf_handle* h) {
     return GPF_OK;
 }
 
+static P2PArgs p2p_args(gpf_handle* h, bool on) {
+    P2PArgs c;
+    c.on = on ? 1 : 0; c.nranks = h->p2p.nranks; c.rank = h->p2p.rank; c.rank_lo = h->p2p.rank_lo; c.rank_hi = h->p2p.rank_hi;
+    for (int r = 0; r < P2P_MAX_RANKS; ++r) c.box[r] = h->p2p.box[r];
+    c.seq = h->p2p.seq; c.qa = h->q[0]; c.qb = h->q[1];
+    return c;
+}
+
 static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, double* slab_out,
-                        hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+                        hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, bool p2p = false) {
     const Layout& L = h->L;
     GPF_TRY(plan_step(h));
     const int mc = h->cfg.mc_order;
@@ -632,38 +649,42 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
         }
     }
     g.g1x = h->g1; g.g1y = h->g1 + 3 * L.pitch;
-    g.arx = h->g1 + 3 * L.pitch + 3 * (L.Nx + 2); g.ary = g.arx + 6 * L.pitch;
     g.st = h->st; g.L = L; g.E = h->E; g.honor_stop = honor_stop;
+    const bool slab = slab_out != nullptr;
     FinishArgs f;
     f.partials = h->partials; f.npartials = np_step + h->nghost_blocks; f.st = h->st;
+    f.log = h->log; f.log_base = log_base; f.log_cap = h->log_cap; f.out = slab_out; f.honor_stop = honor_stop;
+    f.L = L; f.E = h->E;
+    f.p2p = p2p_args(h, p2p);
+    f.arrive = h->arrive; f.msg = slab ? h->halo : nullptr;
+    f.nstep_partials = np_step; f.block_partials = h->block_partials;
     GhostFillArgs gf;
     gf.qa = h->q[0]; gf.qb = h->q[1]; gf.st = h->st; gf.partials = h->partials + np_step;
     gf.L = L; gf.E = h->E; gf.honor_stop = honor_stop;
-    f.log = h->log; f.log_base = log_base; f.log_cap = h->log_cap; f.out = slab_out; f.honor_stop = honor_stop;
-    f.arx = g.arx; f.ary = g.ary; f.g1x = g.g1x; f.g1y = g.g1y; f.L = L; f.E = h->E; f.convert = slab_out ? 0 : 1;
 
+    // Three launches per step:
+    //   k_ghost_stage1  stage-1 values on the downwind ghost row / column (needs the dt the previous step committed)
+    //   k_step          the fused predictor + corrector + average over the interior
+    //   k_ghost_fill    ghost cells of the new field (+ a slab's boundary rows into its message / its peers'
+    //                   mailboxes); its last block to finish reduces all records and commits dt, residual, step
     const int gmax = std::max(L.Nx, L.Ny);
     const dim3 ggrid((gmax + 255) / 256, 2), sgrid((h->nstrips + 3) / 4, h->nchunks);
     const step_kernel_t kstep = step_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, D, topo_mode_of(h));
-    const bool slab = slab_out != nullptr;
-    const int nprep = (L.Nx + L.Ny + 255) / 256;
+    const int nsend = slab ? (6 * L.pitch + 1023) / 1024 : 0;
     EOS_DISPATCH(h->cfg.eos, {
-        if (slab || !h->prepass_valid) {     // stage-1 ghost data from the stored field
-            if (h->Ls) hipLaunchKernelGGL((k_ghost_stage1<EOS_, true>), ggrid, dim3(256), 0, h->stream, g, h->P);
-            else hipLaunchKernelGGL((k_ghost_stage1<EOS_, false>), ggrid, dim3(256), 0, h->stream, g, h->P);
-        }
+        if (h->Ls) hipLaunchKernelGGL((k_ghost_stage1<EOS_, true>), ggrid, dim3(256), 0, h->stream, g, h->P);
+        else hipLaunchKernelGGL((k_ghost_stage1<EOS_, false>), ggrid, dim3(256), 0, h->stream, g, h->P);
         if (ev0) hipEventRecord(ev0, h->stream);
         hipLaunchKernelGGL(kstep, sgrid, dim3(256), 0, h->stream, a, h->P);
         if (ev1) hipEventRecord(ev1, h->stream);
-        if (slab) {
-            hipLaunchKernelGGL((k_ghost_fill<EOS_>), dim3(h->nghost_blocks), dim3(256), 0, h->stream, gf, h->P);
-        } else {                            // ghost cells of this step + stage-1 ghost data of the next one
-            if (h->Ls) hipLaunchKernelGGL((k_edge<EOS_, true>), dim3(h->nghost_blocks + nprep), dim3(256), 0, h->stream, g, gf.partials, h->nghost_blocks, h->P);
-            else hipLaunchKernelGGL((k_edge<EOS_, false>), dim3(h->nghost_blocks + nprep), dim3(256), 0, h->stream, g, gf.partials, h->nghost_blocks, h->P);
-        }
+        hipLaunchKernelGGL((k_ghost_fill<EOS_>), dim3(h->nghost_blocks + nsend), dim3(256), 0, h->stream, gf, f, h->nghost_blocks, h->P);
     });
-    h->prepass_valid = !slab;
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, h->stream, f);
+    if (p2p) {
+        WaitArgs w;
+        w.qa = h->q[0]; w.qb = h->q[1]; w.st = h->st; w.log = h->log; w.log_base = log_base; w.log_cap = h->log_cap;
+        w.L = L; w.E = h->E; w.honor_stop = honor_stop; w.p2p = f.p2p;
+        hipLaunchKernelGGL(k_wait_commit, dim3(1), dim3(1024), 0, h->stream, w);
+    }
     HIP_TRY(hipGetLastError());
     return GPF_OK;
 }
@@ -853,10 +874,7 @@ extern "C" int gpf_step_local(gpf_handle* h, int honor_stop) {
     HIP_TRY(hipSetDevice(h->cfg.device));
     GPF_TRY(ensure_halo(h));
     double* rec = h->halo + (size_t)6 * h->L.pitch;
-    GPF_TRY(enqueue_step(h, honor_stop, h->host_step, rec));
-    hipLaunchKernelGGL(k_halo_pack, dim3((h->L.pitch + 255) / 256), dim3(256), 0, h->stream,
-                       halo_args(h, honor_stop, nullptr, -1, -1));
-    HIP_TRY(hipGetLastError());
+    GPF_TRY(enqueue_step(h, honor_stop, h->host_step, rec));      // leaves rows and record in the message
     return GPF_OK;
 }
 
@@ -871,6 +889,67 @@ extern "C" int gpf_step_commit(gpf_handle* h, int honor_stop, const void* gather
                        (long long)halo_len(h), (long long)6 * h->L.pitch, nranks, h->log, (long long)h->host_step,
                        (long long)h->log_cap, honor_stop);
     HIP_TRY(hipGetLastError());
+    return GPF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// peer-to-peer slab transport
+// ---------------------------------------------------------------------------------------------
+extern "C" int gpf_p2p_export(gpf_handle* h, void* ipc_handle, size_t handle_bytes) {
+    if (!h || !ipc_handle) return fail(GPF_ERR_INVALID, "gpf_p2p_export: null argument");
+    if (handle_bytes != sizeof(hipIpcMemHandle_t)) return fail(GPF_ERR_INVALID, "gpf_p2p_export: the handle buffer must hold 64 bytes");
+    if (h->p2p.on) return fail(GPF_ERR_STATE, "gpf_p2p_export: already connected");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const size_t bytes = p2p_mailbox_bytes(h->L.pitch);
+    if (!h->p2p.mine) {
+        // fine-grained: peers' stores become visible to a kernel that is already running here
+        HIP_TRY(hipExtMallocWithFlags((void**)&h->p2p.mine, bytes, hipDeviceMallocFinegrained));
+    }
+    HIP_TRY(hipMemset(h->p2p.mine, 0, bytes));
+    HIP_TRY(hipDeviceSynchronize());
+    hipIpcMemHandle_t hm;
+    HIP_TRY(hipIpcGetMemHandle(&hm, h->p2p.mine));
+    std::memcpy(ipc_handle, &hm, sizeof(hm));
+    return GPF_OK;
+}
+
+extern "C" int gpf_p2p_connect(gpf_handle* h, int rank, int nranks, const void* ipc_handles, int rank_lo, int rank_hi) {
+    if (!h || !ipc_handles) return fail(GPF_ERR_INVALID, "gpf_p2p_connect: null argument");
+    if (nranks < 1 || nranks > P2P_MAX_RANKS) return fail(GPF_ERR_INVALID, "gpf_p2p_connect: 1 <= nranks <= 16");
+    if (rank < 0 || rank >= nranks || rank_lo >= nranks || rank_hi >= nranks) return fail(GPF_ERR_INVALID, "gpf_p2p_connect: rank out of range");
+    if (!h->p2p.mine) return fail(GPF_ERR_STATE, "gpf_p2p_connect: call gpf_p2p_export first");
+    if (h->p2p.on) return fail(GPF_ERR_STATE, "gpf_p2p_connect: already connected");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const hipIpcMemHandle_t* hs = (const hipIpcMemHandle_t*)ipc_handles;
+    for (int r = 0; r < nranks; ++r) {
+        if (r == rank) { h->p2p.box[r] = h->p2p.mine; continue; }
+        void* p = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&p, hs[r], hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            for (int k = 0; k < r; ++k)
+                if (k != rank && h->p2p.box[k]) { hipIpcCloseMemHandle(h->p2p.box[k]); h->p2p.box[k] = nullptr; }
+            return fail(GPF_ERR_HIP, std::string("gpf_p2p_connect: hipIpcOpenMemHandle(rank ") + std::to_string(r) + "): " + hipGetErrorString(e));
+        }
+        h->p2p.box[r] = (char*)p;
+    }
+    if (!h->p2p.seq) HIP_TRY(hipMalloc((void**)&h->p2p.seq, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(h->p2p.seq, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipDeviceSynchronize());
+    h->p2p.nranks = nranks; h->p2p.rank = rank; h->p2p.rank_lo = rank_lo; h->p2p.rank_hi = rank_hi;
+    h->p2p.on = true;
+    return GPF_OK;
+}
+
+// n whole steps, exchanges included, enqueued without touching the host in between
+extern "C" int gpf_step_p2p(gpf_handle* h, int64_t n, int honor_stop) {
+    if (!h) return fail(GPF_ERR_INVALID, "gpf_step_p2p: null handle");
+    if (!h->pre_run_done) return fail(GPF_ERR_STATE, "gpf_step_p2p: call gpf_pre_run first");
+    if (!h->p2p.on) return fail(GPF_ERR_STATE, "gpf_step_p2p: call gpf_p2p_export / gpf_p2p_connect first");
+    if (n < 0) return fail(GPF_ERR_INVALID, "gpf_step_p2p: n < 0");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    GPF_TRY(ensure_halo(h));
+    double* rec = h->halo + (size_t)6 * h->L.pitch;
+    for (int64_t i = 0; i < n; ++i) GPF_TRY(enqueue_step(h, honor_stop, h->host_step, rec, nullptr, nullptr, true));
     return GPF_OK;
 }
 
@@ -1185,7 +1264,6 @@ extern "C" int gpf_open_step(gpf_handle* h) {
     hipLaunchKernelGGL(k_copy3, dim3(blocks_for(3 * L.plane)), dim3(256), 0, h->stream, h->q[s.parity], h->q[s.parity ^ 1], 3 * L.plane);
     HIP_TRY(hipGetLastError());
     h->step_open = true;
-    h->prepass_valid = false;
     h->host_step = s.step; h->next_step = s.step;
     return GPF_OK;
 }
@@ -1305,3 +1383,4 @@ extern "C" int gpf_close_step_commit(gpf_handle* h, const void* gathered, int nr
     if (out) fill_scalars(s, nullptr, 0.0, out);
     return GPF_OK;
 }
+

@@ -187,6 +187,153 @@ __device__ inline void commit_step(StepState* st, double ekin, double v2, double
 }
 
 // ---------------------------------------------------------------------------------------------
+// finish of the fused step: reduce the per-wave records of k_step and the per-block records of the edge kernel and
+// commit.  Runs in the LAST block of the edge kernel to arrive (finish_if_last), so a step needs no separate launch.
+// ---------------------------------------------------------------------------------------------
+// Peer-to-peer slab transport (one process per GPU, mailboxes mapped into every peer through HIP IPC).
+// A rank's mailbox lives in ITS OWN memory (fine-grained) and is written by its peers over xGMI:
+//     flag[slot][r]     sequence number of rank r's latest message in this slot (release-stored last)
+//     rec[slot][r][8]   rank r's record of the step (Ekin share, max v^2, max c^2, validity flags)
+//     rows[slot][0|1]   the row that fills my row 0 (lower neighbour's last row) / my row Nx+1
+// Two slots alternate with the sequence number: a rank can only send message n+2 after it has seen every
+// rank's message n+1, which those ranks sent after consuming message n -- so slot n%2 is free again.
+// ---------------------------------------------------------------------------------------------
+constexpr long long P2P_TIMEOUT_TICKS = 3000000000ll;       // 30 s of the 100 MHz constant clock
+constexpr int P2P_MAX_RANKS = 16;
+constexpr size_t P2P_ROWS_OFFSET = 4096;      // bytes; header below is 2*16*8 + 2*16*64 = 2304
+struct MailHeader {
+    unsigned long long flag[2][P2P_MAX_RANKS];
+    double rec[2][P2P_MAX_RANKS][8];
+};
+__host__ __device__ inline size_t p2p_mailbox_bytes(int pitch) { return P2P_ROWS_OFFSET + (size_t)2 * 2 * 3 * pitch * sizeof(double); }
+__device__ inline double* p2p_rows(char* box, int slot, int side, int pitch) {
+    return (double*)(box + P2P_ROWS_OFFSET) + (size_t)(slot * 2 + side) * 3 * pitch;
+}
+struct P2PArgs {
+    int on, nranks, rank, rank_lo, rank_hi;   // rank_lo: whose LAST row fills my row 0; rank_hi: whose FIRST row fills my row Nx+1
+    char* box[P2P_MAX_RANKS];                 // every rank's mailbox as mapped here (box[rank] = my own)
+    unsigned long long* seq;                  // messages sent so far by this handle (== received from every peer)
+    const double* qa; const double* qb;
+};
+
+struct FinishArgs {
+    const Partial* partials; int npartials;
+    StepState* st;
+    LogEntry* log; long long log_base, log_cap;
+    double* out;            // if non-null: slab mode, write the 8-double local record here instead of committing
+    int honor_stop;
+    Layout L; Edges E;
+    int nstep_partials;     // the first nstep_partials records come from k_step, the rest from the fill blocks
+    Partial* block_partials;// one record per block of the edge kernel (its slice of k_step's records)
+    unsigned int* arrive;   // blocks of the edge kernel that are done (reset by the last one)
+    double* msg;            // slab, all-gather transport: [first row | last row] of the local message
+    P2PArgs p2p;
+};
+
+// every block of the edge kernel: fold a slice of k_step's per-wave records into one record of its own
+__device__ inline void reduce_slice(const FinishArgs& a, Acc* sm) {
+    const int per = (a.nstep_partials + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int i0 = blockIdx.x * per, i1 = min(i0 + per, a.nstep_partials);
+    Acc acc; acc.zero();
+    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const Partial p = a.partials[i];
+        acc.ekin += p.ekin; acc.v2 = nanmax(acc.v2, p.vmax2); acc.c2 = nanmax(acc.c2, p.c2max); acc.flags |= (int)p.flags;
+    }
+    acc = block_reduce(acc, sm);
+    if (threadIdx.x == 0) {
+        Partial p;
+        p.ekin = acc.ekin; p.vmax2 = acc.v2; p.c2max = acc.c2; p.flags = (double)acc.flags;
+        a.block_partials[blockIdx.x] = p;
+    }
+}
+
+// the last block: combine the blocks' records (slices of k_step's + the fill blocks' own) and commit, or -- slab --
+// publish this rank's record
+__device__ inline void finish_tail(const FinishArgs& a, Acc* sm) {
+    __shared__ double rec_sm[8];
+    StepState* st = a.st;
+    Acc acc; acc.zero();
+    const int nfill = a.npartials - a.nstep_partials, total = (int)gridDim.x + nfill;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const Partial p = i < (int)gridDim.x ? a.block_partials[i] : a.partials[a.nstep_partials + i - (int)gridDim.x];
+        acc.ekin += p.ekin; acc.v2 = nanmax(acc.v2, p.vmax2); acc.c2 = nanmax(acc.c2, p.c2max); acc.flags |= (int)p.flags;
+    }
+    acc = block_reduce(acc, sm);
+    if (threadIdx.x == 0) {
+        if (a.out) {
+            // slab mode: NaN maxima travel as +inf so that any reduction order keeps them
+            const double inf = __builtin_inf();
+            a.out[0] = acc.ekin;
+            a.out[1] = acc.v2 != acc.v2 ? inf : acc.v2;
+            a.out[2] = acc.c2 != acc.c2 ? inf : acc.c2;
+            a.out[3] = (double)acc.flags;
+            a.out[4] = a.out[5] = a.out[6] = a.out[7] = 0.0;
+            for (int k = 0; k < 8; ++k) rec_sm[k] = a.out[k];
+        } else {
+            commit_step(st, acc.ekin, acc.v2, acc.c2, acc.flags, a.log, a.log_base, a.log_cap);
+        }
+    }
+    if (a.p2p.on) {
+        // message n = seq + 1: the rows are on their way (send_rows_block, fenced before the blocks arrived);
+        // now the record to everybody, then the flags
+        __syncthreads();
+        const P2PArgs& c = a.p2p;
+        const unsigned long long n = *c.seq + 1;
+        const int slot = (int)(n & 1);
+        if (threadIdx.x < c.nranks) {
+            MailHeader* hd = (MailHeader*)c.box[threadIdx.x];
+            for (int k = 0; k < 8; ++k) hd->rec[slot][c.rank][k] = rec_sm[k];
+            // same thread, same peer: the release store orders the record (and, through the blocks' own release
+            // fences and the arrive counter, the rows) before the flag
+            __hip_atomic_store(&hd->flag[slot][c.rank], n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// Called by every block of the edge kernel when its own work is done: the last block to arrive finishes the step.
+// Fences are the expensive part here (a device-scope release or acquire costs 1-3 us on this chip: the XCDs' L2s are
+// not coherent with each other), so the hand-over uses exactly one release per block and one acquire.
+__device__ inline void finish_step(const FinishArgs& f, Acc* sm) {
+    __shared__ int last;
+    reduce_slice(f, sm);
+    if (f.p2p.on) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");         // rows stored into a peer's mailbox
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");             // this block's records and ghost cells
+    __syncthreads();
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(f.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(f.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                  // see what the other blocks wrote before they arrived
+    finish_tail(f, sm);
+}
+
+// A slab's first and last owned rows of the field the step has produced, ghost columns included (derived by the
+// y rules, so this does not wait for the fill blocks): into the peers' mailboxes, or into the local all-gather message.
+__device__ inline void send_rows_block(const double* q, const FinishArgs& f, int sblock, int nsblocks) {
+    const Layout& L = f.L;
+    double *dst_first, *dst_last;       // where my FIRST row (-> lower neighbour's row Nx+1) / LAST row goes
+    if (f.p2p.on) {
+        const P2PArgs& c = f.p2p;
+        const int slot = (int)((*c.seq + 1) & 1);
+        dst_first = (c.rank_lo >= 0 && f.E.halo[0]) ? p2p_rows(c.box[c.rank_lo], slot, 1, L.pitch) : nullptr;
+        dst_last = (c.rank_hi >= 0 && f.E.halo[1]) ? p2p_rows(c.box[c.rank_hi], slot, 0, L.pitch) : nullptr;
+    } else {
+        dst_first = f.msg; dst_last = f.msg + 3 * L.pitch;
+    }
+    const int total = 6 * L.pitch;
+    for (int t = sblock * blockDim.x + threadIdx.x; t < total; t += nsblocks * blockDim.x) {
+        const int side = t / (3 * L.pitch), k = (t / L.pitch) % 3, i = t % L.pitch;
+        double* dst = side ? dst_last : dst_first;
+        if (!dst) continue;
+        const int ix = side ? L.Nx : 1, iy = i - L.off;
+        double v = 0.0;
+        if (iy >= 1 && iy <= L.Ny) v = q[k * L.plane + (long long)ix * L.pitch + i];
+        else if (iy == 0 || iy == L.Ny + 1) v = ghost_y(q, L, f.E, iy == 0 ? 2 : 3, k, ix);
+        dst[k * L.pitch + i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // ghost cells of the field k_step has just written (problem.py:576 -> 676-768), in parallel:
 // one thread per ghost cell of the two ghost rows / two ghost columns; the four corners are
 // rule_y(rule_x(.)) exactly as the reference's x-then-y order produces them.  Each block also
@@ -249,106 +396,17 @@ __device__ __forceinline__ void ghost_fill_block(const GhostFillArgs& a, const P
     }
 }
 
+// slab: blocks [0, nfill) fill ghost cells, the rest ship the two boundary rows; the last block done finishes the step
 template <int EOS>
-__global__ __launch_bounds__(256) void k_ghost_fill(const GhostFillArgs a, const Phys P) {
+__global__ __launch_bounds__(256) void k_ghost_fill(const GhostFillArgs a, const FinishArgs f, int nfill, const Phys P) {
     __shared__ Acc sm[4];
     const StepState* st = a.st;
     if (st->invalid != 0 || (a.honor_stop && (st->converged || st->step >= st->max_it))) return;
-    ghost_fill_block<EOS>(a, P, blockIdx.x, gridDim.x, sm);
+    if ((int)blockIdx.x < nfill) ghost_fill_block<EOS>(a, P, blockIdx.x, nfill, sm);
+    else send_rows_block(st->parity ? a.qa : a.qb, f, blockIdx.x - nfill, gridDim.x - nfill);
+    finish_step(f, sm);
 }
 
-// Edge work of one step of an undivided problem, in ONE launch: blocks [0, nfill) write the ghost cells of the new
-// field (k_ghost_fill's job), the others prepare the stage-1 ghost data of the NEXT step from the same new field,
-// deriving any ghost value they need from the interior by the ghost rules -- the two jobs share no data.
-template <int EOS, bool HAS_LS>
-__global__ __launch_bounds__(256) void k_edge(const GhostArgs g, Partial* partials, int nfill, const Phys P) {
-    __shared__ Acc sm[4];
-    const StepState* st = g.st;
-    if (st->invalid != 0 || (g.honor_stop && (st->converged || st->step >= st->max_it))) return;
-    if ((int)blockIdx.x < nfill) {
-        GhostFillArgs f;
-        f.qa = const_cast<double*>(g.qa); f.qb = const_cast<double*>(g.qb); f.st = st; f.partials = partials;
-        f.L = g.L; f.E = g.E; f.honor_stop = g.honor_stop;
-        ghost_fill_block<EOS>(f, P, blockIdx.x, nfill, sm);
-        return;
-    }
-    const Layout& L = g.L;
-    FilledField fld;
-    fld.q = st->parity ? g.qa : g.qb; fld.L = L; fld.E = g.E;
-    const int D = direction_of_step(st, st->step + 1);
-    const int t = (blockIdx.x - nfill) * blockDim.x + threadIdx.x;
-    if (t < L.Ny) ghost_stage1_row<EOS, HAS_LS, false>(fld, g, P, D, t + 1);
-    else if (t - L.Ny < L.Nx) ghost_stage1_col<EOS, HAS_LS, false>(fld, g, P, D, t - L.Ny + 1);
-}
-
-// ---------------------------------------------------------------------------------------------
-// finish of the fused step: reduce the per-wave records of k_step (which already cover the ghost
-// cells it wrote) and commit.  One small block.
-// ---------------------------------------------------------------------------------------------
-struct FinishArgs {
-    const Partial* partials; int npartials;
-    StepState* st;
-    LogEntry* log; long long log_base, log_cap;
-    double* out;            // if non-null: slab mode, write the 8-double local record here instead of committing
-    int honor_stop;
-    // (q, R) pairs parked by k_edge for the next step -> finished stage-1 ghost values, once dt is committed
-    const double* arx; const double* ary; double* g1x; double* g1y;
-    Layout L; Edges E;
-    int convert;
-};
-
-__global__ __launch_bounds__(1024) void k_finish(const FinishArgs a) {
-    __shared__ Acc sm[16];
-    StepState* st = a.st;
-    if (st->invalid != 0 || (a.honor_stop && (st->converged || st->step >= st->max_it))) return;
-    Acc acc; acc.zero();
-    for (int i = threadIdx.x; i < a.npartials; i += blockDim.x) {
-        const Partial p = a.partials[i];
-        acc.ekin += p.ekin; acc.v2 = nanmax(acc.v2, p.vmax2); acc.c2 = nanmax(acc.c2, p.c2max); acc.flags |= (int)p.flags;
-    }
-    acc = block_reduce(acc, sm);
-    if (threadIdx.x == 0) {
-        if (a.out) {
-            // slab mode: NaN maxima travel as +inf so that any reduction order keeps them
-            const double inf = __builtin_inf();
-            a.out[0] = acc.ekin;
-            a.out[1] = acc.v2 != acc.v2 ? inf : acc.v2;
-            a.out[2] = acc.c2 != acc.c2 ? inf : acc.c2;
-            a.out[3] = (double)acc.flags;
-            a.out[4] = a.out[5] = a.out[6] = a.out[7] = 0.0;
-        } else {
-            commit_step(st, acc.ekin, acc.v2, acc.c2, acc.flags, a.log, a.log_base, a.log_cap);
-        }
-    }
-    if (!a.convert) return;
-    __threadfence_block();
-    __syncthreads();                // thread 0's commit (dt, step) is visible to the block
-    if (st->invalid) return;
-    const double dt = st->dt;
-    const int D = direction_of_step(st, st->step);          // the step that will consume these values
-    const int ex = D > 0 ? 1 : 0, ey = D > 0 ? 3 : 2;
-    const Layout& L = a.L;
-    const double* __restrict__ arx = a.arx;
-    const double* __restrict__ ary = a.ary;
-    double* __restrict__ g1x = a.g1x;
-    double* __restrict__ g1y = a.g1y;
-    // rules hoisted out of the loops: 1 = Dirichlet (2 T - v), else copy
-    double sgn_x[3], add_x[3], sgn_y[3], add_y[3];
-    for (int c = 0; c < 3; ++c) {
-        const bool dx_ = a.E.rule[ex][c] == BC_D, dy_ = a.E.rule[ey][c] == BC_D;
-        sgn_x[c] = dx_ ? -1.0 : 1.0; add_x[c] = dx_ ? 2.0 * a.E.value[ex] : 0.0;
-        sgn_y[c] = dy_ ? -1.0 : 1.0; add_y[c] = dy_ ? 2.0 * a.E.value[ey] : 0.0;
-    }
-    for (int c = 0; c < 3; ++c) {
-        const int bx = c * L.pitch + L.off + 1, by = c * (L.Nx + 2) + 1;
-#pragma unroll 4
-        for (int i = threadIdx.x; i < L.Ny; i += blockDim.x)
-            g1x[bx + i] = add_x[c] + sgn_x[c] * (arx[bx + i] - dt * arx[bx + i + 3 * L.pitch]);
-#pragma unroll 4
-        for (int i = threadIdx.x; i < L.Nx; i += blockDim.x)
-            g1y[by + i] = add_y[c] + sgn_y[c] * (ary[by + i] - dt * ary[by + i + 3 * (L.Nx + 2)]);
-    }
-}
 
 // slab mode.  Every rank contributes ONE message per step to a single all-gather:
 //     [ first interior row (3 x pitch) | last interior row (3 x pitch) | 8-double record ]
@@ -384,6 +442,74 @@ __global__ void k_halo_unpack(const HaloArgs a) {
         if (a.E.halo[0] && a.rank_lo >= 0) q[c * a.L.plane + i] = a.gathered[a.rank_lo * len + (3 + c) * a.L.pitch + i];
         if (a.E.halo[1] && a.rank_hi >= 0)
             q[c * a.L.plane + (long long)(a.L.Nx + 1) * a.L.pitch + i] = a.gathered[a.rank_hi * len + c * a.L.pitch + i];
+    }
+}
+
+// Receiving side of the peer-to-peer transport: wait (bounded) for message seq+1 of every rank, scatter the two
+// neighbour rows into my outer rows, reduce the records in rank order and commit -- no host, no collective library.
+constexpr int INVALID_PEER_TIMEOUT = 3;
+struct WaitArgs {
+    double* qa; double* qb;
+    StepState* st;
+    LogEntry* log; long long log_base, log_cap;
+    Layout L; Edges E;
+    int honor_stop;
+    P2PArgs p2p;
+};
+__global__ __launch_bounds__(1024) void k_wait_commit(const WaitArgs a) {
+    __shared__ int missing;
+    StepState* st = a.st;
+    if (st->invalid != 0 || (a.honor_stop && (st->converged || st->step >= st->max_it))) return;
+    const P2PArgs& c = a.p2p;
+    const unsigned long long n = *c.seq + 1;
+    const int slot = (int)(n & 1);
+    MailHeader* hd = (MailHeader*)c.box[c.rank];
+    if (threadIdx.x == 0) missing = 0;
+    __syncthreads();
+    if (threadIdx.x < c.nranks) {
+        const long long t0 = wall_clock64();
+        bool ok = false;
+        while (!ok && wall_clock64() - t0 < P2P_TIMEOUT_TICKS) {
+            ok = __hip_atomic_load(&hd->flag[slot][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= n;
+            if (!ok) __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok) atomicAdd(&missing, 1);
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);    // once, after the flag has been seen (not on every probe)
+    }
+    __syncthreads();
+    if (missing) {                      // a peer never delivered: stop this handle instead of spinning forever
+        if (threadIdx.x == 0) st->invalid = INVALID_PEER_TIMEOUT;
+        return;
+    }
+    const Layout& L = a.L;
+    double* q = st->parity ? a.qa : a.qb;
+    if (c.rank_lo >= 0 && a.E.halo[0]) {
+        const double* src = p2p_rows(c.box[c.rank], slot, 0, L.pitch);
+        for (int k = 0; k < 3; ++k)
+            for (int i = threadIdx.x; i < L.pitch; i += blockDim.x)
+                q[k * L.plane + i] = __builtin_nontemporal_load(src + k * L.pitch + i);
+    }
+    if (c.rank_hi >= 0 && a.E.halo[1]) {
+        const double* src = p2p_rows(c.box[c.rank], slot, 1, L.pitch);
+        for (int k = 0; k < 3; ++k)
+            for (int i = threadIdx.x; i < L.pitch; i += blockDim.x)
+                q[k * L.plane + (long long)(L.Nx + 1) * L.pitch + i] = __builtin_nontemporal_load(src + k * L.pitch + i);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ekin = 0.0, v2 = 0.0, c2 = 0.0;
+        int flags = 0;
+        for (int r = 0; r < c.nranks; ++r) {
+            const double* p = hd->rec[slot][r];
+            ekin += p[0];
+            v2 = fmax(v2, p[1]); c2 = fmax(c2, p[2]);
+            flags |= (int)p[3];
+        }
+        const double inf = __builtin_inf();
+        if (v2 == inf) v2 = __builtin_nan("");
+        if (c2 == inf) c2 = __builtin_nan("");
+        *c.seq = n;
+        commit_step(st, ekin, v2, c2, flags, a.log, a.log_base, a.log_cap);
     }
 }
 

@@ -265,9 +265,7 @@ __global__ __launch_bounds__(256) void k_step(const StepArgs a, const Phys P) {
 //   Neumann  : q1(ghost) = q1(adjacent)                (problem.py:766)
 //   Dirichlet: q1(ghost) = 2*target - q1(adjacent)     (problem.py:758-764)
 // q1 at the source cell is the ordinary predictor result there: q1 = q - dt R.  k_step reads finished ghost values
-// g1 = rule(q - dt R).  The stand-alone prepass writes them directly; in the steady loop the dt-independent pair
-// (q, R) of step n+1 is computed as soon as the field of step n is complete -- before its dt is known -- in the
-// same launch as the ghost fill of step n (k_edge), and k_finish turns it into g1 once it has committed dt.
+// g1 = rule(q - dt R), written by k_ghost_stage1 at the start of every step.
 // ---------------------------------------------------------------------------------------------
 struct GhostArgs {
     const double* qa; const double* qb;
@@ -275,7 +273,6 @@ struct GhostArgs {
     const double* seam[2];      // per x edge: [2 rows][4: h,hx,hy,Ls][pitch] = topography of (source row, its
                                 // upwind row) on the far side of a periodic slab seam, or nullptr
     double* g1x; double* g1y;   // finished ghost values [3][pitch], [3][Nx+2]
-    double* arx; double* ary;   // (q, R) pairs [6][pitch], [6][Nx+2] awaiting dt
     const StepState* st;
     Layout L; Edges E;
     int honor_stop;
@@ -287,27 +284,6 @@ struct StoredField {
     const double* q; Layout L;
     __device__ __forceinline__ double get(int ix, int iy, int c) const { return q[c * L.plane + L.at(ix, iy)]; }
 };
-// The interior of a freshly written field with its physical ghost cells derived on the fly by the ghost rules
-// (x rule, then y rule: the reference's order, so corners agree) -- what k_ghost_fill is writing concurrently.
-struct FilledField {
-    const double* q; Layout L; Edges E;
-    __device__ __forceinline__ double get(int ix, int iy, int c) const {
-        int sx = ix, sy = iy, ex = -1, ey = -1;
-        if (ix == 0 || ix == L.Nx + 1) {
-            ex = ix == 0 ? 0 : 1;
-            sx = E.rule[ex][0] == BC_P ? (ex == 0 ? L.Nx : 1) : (ex == 0 ? 1 : L.Nx);
-        }
-        if (iy == 0 || iy == L.Ny + 1) {
-            ey = iy == 0 ? 2 : 3;
-            sy = E.rule[ey][0] == BC_P ? (ey == 2 ? L.Ny : 1) : (ey == 2 ? 1 : L.Ny);
-        }
-        double v = q[c * L.plane + L.at(sx, sy)];
-        if (ex >= 0) v = ghost_rule(E, ex, c, v);
-        if (ey >= 0) v = ghost_rule(E, ey, c, v);
-        return v;
-    }
-};
-
 template <int EOS, bool HAS_LS, class Field>
 __device__ __forceinline__ void stage1_rate(const Field& fld, const GhostArgs& a, const Phys& P, int D, int ix, int iy,
                                             const double* tsrc, const double* tup, const double* lsrc, const double* lup,
@@ -342,8 +318,7 @@ __device__ __forceinline__ void stage1_rate(const Field& fld, const GhostArgs& a
 }
 
 // one interior column iy of the downwind ghost ROW
-// FINAL: write rule(q - dt R) into g1 (dt known); otherwise park (q, R) in ar
-template <int EOS, bool HAS_LS, bool FINAL, class Field>
+template <int EOS, bool HAS_LS, class Field>
 __device__ __forceinline__ void ghost_stage1_row(const Field& fld, const GhostArgs& a, const Phys& P, int D, int iy) {
     const Layout& L = a.L;
     const int edge = D > 0 ? 1 : 0;
@@ -367,18 +342,11 @@ __device__ __forceinline__ void ghost_stage1_row(const Field& fld, const GhostAr
     }
     double A[3], R[3];
     stage1_rate<EOS, HAS_LS>(fld, a, P, D, ix_src, iy, ts, tu, ls, lu, ix_up, A, R);
-    for (int c = 0; c < 3; ++c) {
-        if (FINAL) {
-            a.g1x[c * L.pitch + L.off + iy] = ghost_rule(a.E, edge, c, A[c] - a.st->dt * R[c]);
-        } else {
-            a.arx[c * L.pitch + L.off + iy] = A[c];
-            a.arx[(3 + c) * L.pitch + L.off + iy] = R[c];
-        }
-    }
+    for (int c = 0; c < 3; ++c) a.g1x[c * L.pitch + L.off + iy] = ghost_rule(a.E, edge, c, A[c] - a.st->dt * R[c]);
 }
 
 // one interior row ix of the downwind ghost COLUMN
-template <int EOS, bool HAS_LS, bool FINAL, class Field>
+template <int EOS, bool HAS_LS, class Field>
 __device__ __forceinline__ void ghost_stage1_col(const Field& fld, const GhostArgs& a, const Phys& P, int D, int ix) {
     const Layout& L = a.L;
     const int edge = D > 0 ? 3 : 2;
@@ -386,17 +354,10 @@ __device__ __forceinline__ void ghost_stage1_col(const Field& fld, const GhostAr
     const int iy_src = periodic ? (D > 0 ? 1 : L.Ny) : (D > 0 ? L.Ny : 1);
     double A[3], R[3];
     stage1_rate<EOS, HAS_LS>(fld, a, P, D, ix, iy_src, nullptr, nullptr, nullptr, nullptr, ix - D, A, R);
-    for (int c = 0; c < 3; ++c) {
-        if (FINAL) {
-            a.g1y[c * (L.Nx + 2) + ix] = ghost_rule(a.E, edge, c, A[c] - a.st->dt * R[c]);
-        } else {
-            a.ary[c * (L.Nx + 2) + ix] = A[c];
-            a.ary[(3 + c) * (L.Nx + 2) + ix] = R[c];
-        }
-    }
+    for (int c = 0; c < 3; ++c) a.g1y[c * (L.Nx + 2) + ix] = ghost_rule(a.E, edge, c, A[c] - a.st->dt * R[c]);
 }
 
-// stand-alone prepass from the STORED field: first step after an upload, and every step of a slab
+// stage-1 ghost data of the step about to run, from the stored field (ghost cells and halo rows included)
 template <int EOS, bool HAS_LS>
 __global__ __launch_bounds__(256) void k_ghost_stage1(const GhostArgs a, const Phys P) {
     if (halted(a.st, a.honor_stop)) return;
@@ -406,9 +367,9 @@ __global__ __launch_bounds__(256) void k_ghost_stage1(const GhostArgs a, const P
     const int D = predictor_direction(a.st);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.y == 0) {
-        if (t + 1 <= L.Ny) ghost_stage1_row<EOS, HAS_LS, true>(fld, a, P, D, t + 1);
+        if (t + 1 <= L.Ny) ghost_stage1_row<EOS, HAS_LS>(fld, a, P, D, t + 1);
     } else {
-        if (t + 1 <= L.Nx) ghost_stage1_col<EOS, HAS_LS, true>(fld, a, P, D, t + 1);
+        if (t + 1 <= L.Nx) ghost_stage1_col<EOS, HAS_LS>(fld, a, P, D, t + 1);
     }
 }
 

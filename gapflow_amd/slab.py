@@ -24,6 +24,7 @@ gloo to check partitioning, message pairing and the rank-ordered reduction.
 import ctypes as C
 import io as _io
 import os
+import sys
 from copy import deepcopy
 
 import numpy as np
@@ -100,6 +101,7 @@ class SlabDriver:
         self.graph = None
         self.graph_honor = None
         self.use_graph = os.environ.get('GPF_SLAB_GRAPH', '0') == '1' and self.message.is_cuda
+        self.p2p = False                # True: the step's own kernels exchange rows and records (gpf_step_p2p)
 
     def _eager(self, n, honor_stop):
         for _ in range(n):
@@ -132,6 +134,10 @@ class SlabDriver:
     def advance(self, n, honor_stop=False):
         """n time steps; with GPF_SLAB_GRAPH=1 pairs of steps are replayed from a captured hipGraph, which takes
         the per-step host dispatch (two library calls and one collective) off the critical path."""
+        if self.p2p:
+            self.engine.step_p2p(n, honor_stop)
+            self.enqueued += n
+            return
         if not self.use_graph or n < 6:
             return self._eager(n, honor_stop)
         if self.enqueued == 0:
@@ -174,6 +180,9 @@ class HipSlabEngine:
     def commit(self, gathered, honor_stop, rank_lo, rank_hi):
         _lib.check(self.lib.gpf_step_commit(self.h, int(honor_stop), C.c_void_p(gathered.data_ptr()), self.world,
                                             int(rank_lo), int(rank_hi)))
+
+    def step_p2p(self, n, honor_stop):
+        _lib.check(self.lib.gpf_step_p2p(self.h, int(n), int(honor_stop)))
 
     def set_stream(self, stream_ptr):
         _lib.check(self.lib.gpf_set_stream(self.h, C.c_void_p(stream_ptr)))
@@ -249,6 +258,33 @@ class SlabProblem:
             self._gp_models = attach_surrogates(self, gp, self.database, cls=SlabSurrogate)
             self._pair = torch.zeros(8, dtype=torch.float64, device='cuda')
             self._pairs = torch.zeros(8 * self.world, dtype=torch.float64, device='cuda')
+
+        if os.environ.get('GPF_SLAB_TRANSPORT', 'rccl') == 'p2p':
+            if not self.connect_p2p():
+                raise RuntimeError("GPF_SLAB_TRANSPORT=p2p: the peers' mailboxes could not be mapped (HIP IPC)")
+
+    def connect_p2p(self):
+        """Switch the fused slab step to the peer-to-peer transport (ranks of one node): exchange the mailboxes'
+        IPC handles once through the process group, map them, and from then on `advance` enqueues whole batches of
+        steps whose kernels talk to each other directly.  Collective; returns False (and stays on the all-gather
+        transport) unless every rank succeeded."""
+        t, L = self.torch, self.layout
+        buf = (C.c_ubyte * 64)()
+        ok = self.lib.gpf_p2p_export(self._h, buf, 64) == 0
+        mine = t.tensor(list(buf), dtype=t.uint8).to('cuda')
+        everyone = t.zeros(64 * self.world, dtype=t.uint8, device='cuda')
+        self.dist.all_gather_into_tensor(everyone, mine)
+        if ok:
+            handles = everyone.cpu().numpy().tobytes()
+            d = self.driver
+            ok = self.lib.gpf_p2p_connect(self._h, self.rank, self.world, handles, d.rank_lo, d.rank_hi) == 0
+        if not ok:
+            print(f"[gapflow_amd] rank {self.rank}: peer-to-peer transport unavailable: "
+                  f"{self.lib.gpf_last_error().decode()}", file=sys.stderr)
+        flag = t.tensor([1.0 if ok else 0.0], dtype=t.float64, device='cuda')
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        self.driver.p2p = bool(flag.item() == 1.0)
+        return self.driver.p2p
 
     def __del__(self):
         h = getattr(self, '_h', None)
@@ -368,6 +404,8 @@ class SlabProblem:
     def state(self):
         sc = _lib.GpfScalars()
         _lib.check(self.lib.gpf_state(self._h, C.byref(sc)))
+        if sc.invalid == 3:
+            raise RuntimeError("slab step: a peer rank did not deliver its rows within 30 s (peer-to-peer transport)")
         return sc
 
     def local_q(self):

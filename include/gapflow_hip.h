@@ -166,6 +166,17 @@ int gpf_set_dt(gpf_handle* h, double dt);
 int gpf_slab_message(gpf_handle* h, void** message, size_t* count);
 int gpf_step_local(gpf_handle* h, int honor_stop);
 int gpf_step_commit(gpf_handle* h, int honor_stop, const void* gathered, int nranks, int rank_lo, int rank_hi);
+/* Peer-to-peer slab transport (GPUs of one node, one process each).  Instead of a collective library the step's own
+ * kernels store the two boundary rows and the 64-byte record straight into the peers' mailboxes (device memory mapped
+ * through HIP IPC, xGMI underneath) and the receiving kernel polls a sequence flag -- no host and no extra launches
+ * between steps, so gpf_step_p2p(n) enqueues n complete steps at once.
+ *   gpf_p2p_export   allocate this slab's mailbox, return its 64-byte IPC handle (exchange them with any transport)
+ *   gpf_p2p_connect  map every rank's mailbox; ipc_handles = nranks x 64 bytes in rank order
+ *   gpf_step_p2p     n steps; a peer that stays silent for 30 s marks the state invalid (gpf_state: invalid == 3)
+ * rank_lo / rank_hi as in gpf_step_commit. */
+int gpf_p2p_export(gpf_handle* h, void* ipc_handle, size_t handle_bytes);
+int gpf_p2p_connect(gpf_handle* h, int rank, int nranks, const void* ipc_handles, int rank_lo, int rank_hi);
+int gpf_step_p2p(gpf_handle* h, int64_t n, int honor_stop);
 /* Stage-wise step of a slab (GP closures, shear thinning): after each gpf_stage_advance the rows a neighbour needs
  * are packed from the working field (gpf_stage_message -> the same message buffer), all-gathered by the caller and
  * scattered (gpf_stage_absorb); gpf_close_step_local averages, applies the local ghost rules and leaves this slab's

@@ -43,7 +43,9 @@ def test_one_rank_group_equals_serial_problem(hiplib, graph, monkeypatch):
         serial._pre_run()
         serial._advance(20, honor_stop=False)
         assert st.step == 20 and st.invalid == 0
-        assert st.dt == serial.dt and st.residual == serial.residual
+        assert st.dt == serial.dt
+        # Ekin is summed over a different block partition (the slab launches extra row-shipping blocks)
+        np.testing.assert_allclose(st.residual, serial.residual, rtol=1e-9)
         np.testing.assert_array_equal(slab.local_q(), serial.q)
     finally:
         dist.destroy_process_group()
@@ -79,7 +81,7 @@ class StagedGloo:
         t.copy_(c)
 
 
-def _slab_worker(rank, world, port, text, nsteps, out_dir):
+def _slab_worker(rank, world, port, text, nsteps, out_dir, p2p=False):
     import torch
     import torch.distributed as dist
     from gapflow_amd.slab import SlabProblem
@@ -88,6 +90,8 @@ def _slab_worker(rank, world, port, text, nsteps, out_dir):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         slab = SlabProblem.from_string(text, device=0, dist=StagedGloo(dist, torch))
+        if p2p:
+            assert slab.connect_p2p(), 'HIP IPC mapping of the peers\' mailboxes failed'
         slab.pre_run()
         slab.advance(nsteps)
         st = slab.state()
@@ -108,9 +112,12 @@ properties: {EOS: DH, shear: 0.0794, bulk: 0., rho0: 877.7007}
 """
 
 
+@pytest.mark.parametrize('p2p', [False, True], ids=['allgather', 'p2p'])
 @pytest.mark.parametrize('text,world', [(SIM, 2), (SIM, 3), (DIRICHLET, 2), (DIRICHLET, 3)])
-def test_multi_rank_engine_matches_serial(hiplib, tmp_path, text, world):
-    """2 and 3 processes sharing this GPU, each owning an x-slab: assembled result == the one-handle run."""
+def test_multi_rank_engine_matches_serial(hiplib, tmp_path, text, world, p2p):
+    """2 and 3 processes sharing this GPU, each owning an x-slab: assembled result == the one-handle run.
+    `p2p`: rows and records travel through IPC-mapped mailboxes written and polled by the step's own kernels
+    (the all-gather variant moves them through the process group)."""
     import torch.multiprocessing as mp
     from gapflow_amd import Problem
     nsteps = 20
@@ -118,7 +125,7 @@ def test_multi_rank_engine_matches_serial(hiplib, tmp_path, text, world):
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_slab_worker, args=(world, port, text, nsteps, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_slab_worker, args=(world, port, text, nsteps, str(tmp_path), p2p), nprocs=world, join=True)
     serial = Problem.from_string(text)
     serial._pre_run()
     serial._advance(nsteps, honor_stop=False)
