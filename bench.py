@@ -156,9 +156,9 @@ def run_single(args):
 
 
 def run_slabs(args, rank, world):
-    """N x-slabs, one rank per GPU.  The K steps are timed twice: with the per-step host dispatch (library call,
-    RCCL all-gather, library call) and -- guarded by a watchdog, because it cannot be rehearsed on a one-GPU box --
-    with pairs of steps replayed from a captured hipGraph.  Rank 0 reports the faster of the two complete runs."""
+    """N x-slabs, one rank per GPU.  The same K steps are timed up to three times: host-dispatched with one RCCL
+    all-gather per step (the conservative transport), with the peer-to-peer mailbox transport, and with the all-gather
+    steps replayed from a hipGraph.  Rank 0 reports the fastest run that completed and reproduced the first one."""
     import threading
     import torch
     import torch.distributed as dist
@@ -203,35 +203,74 @@ def run_slabs(args, rank, world):
         wall = timed(prob, args.steps)
         st = prob.state()
         assert st.step == args.warmup + args.steps and st.invalid == 0, "steps were skipped inside the timed region"
-    best = line(wall, "eager")
+    best = line(wall, "host-dispatched steps, RCCL all-gather")
+    st_ref = (int(st.step), float(st.dt), float(st.ekin))
 
-    if os.environ.get('GPF_BENCH_TRY_GRAPH', '1') == '1':
-        def give_up():          # a wedged collective cannot be interrupted: report what is already measured
-            if rank == 0:
-                _emit(best)
-            os._exit(0)
-        dog = threading.Timer(float(os.environ.get('GPF_BENCH_GRAPH_TIMEOUT', 120)), give_up)
+    # Two faster ways to run the same K steps follow.  Neither can be rehearsed across GPUs on the one-GPU development
+    # box, so each runs behind a watchdog and counts only if it finishes, reproduces the run above (same step count,
+    # dt and kinetic energy) on every rank, and is faster.
+    def give_up():              # a wedged exchange cannot be interrupted: report what is already measured
+        if rank == 0:
+            _emit(best)
+        os._exit(0)
+
+    def same_run(s2, steps):
+        ok = (int(s2.step) == steps and s2.invalid == 0 and abs(s2.dt - st_ref[1]) <= 1e-12 * st_ref[1]
+              and abs(s2.ekin - st_ref[2]) <= 1e-10 * st_ref[2])
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t.item()) == 1.0
+
+    def attempt(name, fn):
+        nonlocal best
+        dog = threading.Timer(float(os.environ.get('GPF_BENCH_ATTEMPT_TIMEOUT', 120)), give_up)
         dog.daemon = True
         dog.start()
         try:
             with contextlib.redirect_stdout(sys.stderr):
-                prob.driver.use_graph = True
-                prob.advance(8)                                    # captures
-                wall_g = timed(prob, args.steps)
-                st = prob.state()
-                ok = torch.tensor([1.0 if (st.step == args.warmup + 2 * args.steps + 8 and st.invalid == 0) else 0.0],
-                                  dtype=torch.float64, device='cuda')
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if float(ok.item()) == 1.0 and wall_g < wall:
-                best = line(wall_g, "hipGraph replay of step pairs")
-                best["config"]["eager_ms_per_step"] = wall / args.steps * 1e3
-        except Exception as e:      # noqa: BLE001 -- any failure here leaves the eager measurement standing
-            print(f"[bench] graph replay not used: {type(e).__name__}: {e}", file=sys.stderr)
+                fn()
+        except Exception as e:      # noqa: BLE001 -- any failure here leaves the measured line standing
+            print(f"[bench] {name} not used: {type(e).__name__}: {e}", file=sys.stderr)
             dog.cancel()
             if rank == 0:
                 _emit(best)
-            os._exit(0)
+            os._exit(0)             # peers may be stuck in a collective this rank will never join
         dog.cancel()
+
+    def try_p2p():
+        # the step's own kernels write rows and records into the peers' IPC-mapped mailboxes (gapflow_amd/slab.py)
+        nonlocal best
+        p2 = SlabProblem.from_string(WORKLOAD_YAML.format(N=N_GRID), device=local)
+        if not p2.connect_p2p():
+            return
+        p2.pre_run()
+        p2.advance(args.warmup)
+        wall_p = timed(p2, args.steps)
+        if same_run(p2.state(), args.warmup + args.steps) and wall_p < wall:
+            cand = line(wall_p, "device-driven steps, peer-to-peer mailboxes over xGMI (no collective library)")
+            cand["config"]["parallelism"] = (f"{world} x-slabs; per step each GPU stores 2 boundary rows into its "
+                                             "neighbours' memory and a 64-B record into everyone's, then polls")
+            cand["config"]["rccl_allgather_ms_per_step"] = wall / args.steps * 1e3
+            best = cand
+
+    def try_graph():
+        nonlocal best
+        prob.driver.use_graph = True
+        prob.advance(8)                                    # captures
+        wall_g = timed(prob, args.steps)
+        s2 = prob.state()
+        ok = torch.tensor([1.0 if (s2.step == args.warmup + 2 * args.steps + 8 and s2.invalid == 0) else 0.0],
+                          dtype=torch.float64, device='cuda')
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) == 1.0 and wall_g * 1e3 / args.steps < best["ms_per_step"]:
+            cand = line(wall_g, "hipGraph replay of step pairs, RCCL all-gather")
+            cand["config"]["eager_ms_per_step"] = wall / args.steps * 1e3
+            best = cand
+
+    if os.environ.get('GPF_BENCH_TRY_P2P', '1') == '1':
+        attempt("peer-to-peer transport", try_p2p)
+    if os.environ.get('GPF_BENCH_TRY_GRAPH', '1') == '1':
+        attempt("graph replay", try_graph)
     dist.barrier()
     dist.destroy_process_group()
     return best if rank == 0 else None

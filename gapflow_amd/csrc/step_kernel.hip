@@ -203,7 +203,7 @@ __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, con
                     r_ekin += w * (v2 * 0.5);
                     // Flags instead of NaN-propagating maxima in the hot loop: a NaN in any component makes v2 NaN
                     // (flag 1: the state is invalid and the step is undone, problem.py:319-332, so the maxima are
-                    // then irrelevant); an imaginary sound speed raises flag 4 and k_finish turns c2max into NaN,
+                    // then irrelevant); an imaginary sound speed raises flag 4 and commit_step turns c2max into NaN,
                     // which is what np.sqrt(...).max() yields in the reference (stress.py:539).
                     r_v2 = fmax(r_v2, v2);
                     if (v2 != v2) r_flags |= 1;
