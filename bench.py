@@ -101,35 +101,41 @@ def cpu_baseline(sample_n=2048, steps=10):
                       f"{os.cpu_count()} cores), same YAML at {sample_n}x{sample_n}, {steps} steps, {dt:.1f} s"}
 
 
-def run_single(args):
+def time_problem(text, steps, warmup):
+    """(wall seconds of `steps` steps, k_step ms per launch, all kernels ms per step) for one YAML input."""
     import ctypes as C
     from gapflow_amd import Problem, _lib
     with contextlib.redirect_stdout(sys.stderr):
-        prob = Problem.from_string(WORKLOAD_YAML.format(N=N_GRID))
+        prob = Problem.from_string(text)
         prob._pre_run()
         lib = prob._lib
-        if args.warmup > 0:
-            prob._advance(args.warmup, honor_stop=False)
+        if warmup > 0:
+            prob._advance(warmup, honor_stop=False)
         # --- timed region: K steps enqueued back to back, one host sync at the end ---
         nexec = C.c_int64(0)
         _lib.check(lib.gpf_scalars(prob._h, C.byref(_lib.GpfScalars())))      # drains the stream
         t0 = time.perf_counter()
         done = 0
-        while done < args.steps:
-            n = min(4096, args.steps - done)
+        while done < steps:
+            n = min(4096, steps - done)
             _lib.check(lib.gpf_step(prob._h, n, 0, None, 0, C.byref(nexec)))    # returns after a stream sync
             done += n
         t1 = time.perf_counter()
-        assert int(nexec.value) == args.warmup + args.steps, "steps were skipped inside the timed region"
+        assert int(nexec.value) == warmup + steps, "steps were skipped inside the timed region"
         # --- kernel time of the dominant kernel, HIP events on the launch stream ---
         kt, tt = C.c_double(0), C.c_double(0)
-        nk = min(max(args.steps, 1), 200)
+        nk = min(max(steps, 1), 200)
         _lib.check(lib.gpf_step_timed(prob._h, nk, C.byref(kt), C.byref(tt)))
         sc = prob._scalars()
         assert sc.invalid == 0 and sc.ekin == sc.ekin, "state went invalid during the benchmark"
-    wall = t1 - t0
+        del prob
+    return t1 - t0, kt.value / nk, tt.value / nk
+
+
+def run_single(args):
+    wall, kernel_ms, all_ms = time_problem(WORKLOAD_YAML.format(N=N_GRID), args.steps, args.warmup)
     cells = N_GRID * N_GRID
-    kernel_s = kt.value / nk / 1e3
+    kernel_s = kernel_ms / 1e3
     achieved = BYTES_PER_CELL * cells / kernel_s / 1e9
     traffic, traffic_src = measured_traffic()
     out = {
@@ -143,13 +149,24 @@ def run_single(args):
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "k_step<DH>",
                      "kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_launch": BYTES_PER_CELL * cells,
-                     "all_kernels_ms_per_step": tt.value / nk,
+                     "all_kernels_ms_per_step": all_ms,
                      "note": "algorithmic bytes follow SURVEY.md 8(d): 72 B per cell-update (q read + topography read + "
                              "q write).  The journal-bearing gap varies along x only, and the kernel then reads the "
                              "topography as one (h, hx, hy) triple per row instead of three planes (GPF_TOPO_PLANES=1 "
                              "disables this): its actual HBM traffic (`traffic`) is below the algorithmic figure, and "
                              "against the 48 B per cell-update that remain compulsory the fraction is achieved*48/72/peak."},
     }
+    if not args.no_variants:
+        # the journal gap is y-invariant, so also time a gap that varies in both directions with a
+        # cross flow (all three topography planes are read: the full 72 B per cell-update are compulsory there)
+        text = WORKLOAD_YAML.format(N=N_GRID).replace("type: journal\n    CR: 1.e-2\n    eps: 0.7\n    U: 0.1\n    V: 0.",
+                                                      "type: asperity\n    hmin: 2.e-6\n    hmax: 1.e-5\n    num: 1\n    U: 0.1\n    V: 0.05")
+        assert 'asperity' in text
+        w2, k2, a2 = time_problem(text, args.steps, args.warmup)
+        g2 = BYTES_PER_CELL * cells / (k2 / 1e3) / 1e9
+        out["variants"] = {"asperity_gap_2d_V0.05": {
+            "value": cells * args.steps / w2 / 1e6, "unit": "Mcell-updates/s", "ms_per_step": w2 / args.steps * 1e3,
+            "kernel_ms": k2, "roofline_achieved_GBps": g2, "roofline_frac": g2 / HBM_PEAK_GBS}}
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline()
     return out
@@ -285,6 +302,7 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    ap.add_argument('--no-variants', action='store_true', help='skip the 2-D-gap variant of the workload')
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

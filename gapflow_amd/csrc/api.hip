@@ -60,7 +60,8 @@ struct gpf_handle {
     double* halo = nullptr;                 // this slab's all-gather message: first row, last row (3 x pitch each), 8-double record
     StepState* st = nullptr;
     Partial* partials = nullptr;
-    unsigned int* arrive = nullptr;         // blocks of k_ghost_fill that are done (finish_step)
+    unsigned int* arrive = nullptr;         // [0] blocks of k_ghost_fill that are done (finish_step), [1] same for k_begin_p2p
+    bool g1_ready = false;                  // g1 already holds the next step's stage-1 ghost values (k_begin_p2p wrote them)
     Partial* block_partials = nullptr;      // one record per edge-kernel block
     int npartials = 0, nstrips = 0, nchunks = 0, rows_per_chunk = 0, nghost_blocks = 0;
     ScalarPartial* spart = nullptr;         // k_scalars block records (+ 4 totals at the end)
@@ -263,8 +264,8 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
     h->nghost_blocks = std::max(1, std::min(64, (2 * (L.Ny + 2) + 2 * L.Nx + 255) / 256));
     HIP_TRY_C(hipMalloc(&h->partials, (size_t)(h->npartials + h->nghost_blocks) * sizeof(Partial)));
     HIP_TRY_C(hipMemset(h->partials, 0, (size_t)(h->npartials + h->nghost_blocks) * sizeof(Partial)));
-    HIP_TRY_C(hipMalloc(&h->arrive, sizeof(unsigned int)));
-    HIP_TRY_C(hipMemset(h->arrive, 0, sizeof(unsigned int)));
+    HIP_TRY_C(hipMalloc(&h->arrive, 2 * sizeof(unsigned int)));
+    HIP_TRY_C(hipMemset(h->arrive, 0, 2 * sizeof(unsigned int)));
     HIP_TRY_C(hipMalloc(&h->block_partials, 1024 * sizeof(Partial)));
     h->nspart = 1024;
     HIP_TRY_C(hipMalloc(&h->spart, (size_t)(h->nspart + 8) * sizeof(ScalarPartial)));
@@ -386,6 +387,7 @@ extern "C" int gpf_upload(gpf_handle* h, int field, const double* host, size_t c
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (field == GPF_FIELD_Q) h->has_q = true;
+    h->g1_ready = false;
     if (field == GPF_FIELD_TOPO) h->has_topo = true;
     return GPF_OK;
 }
@@ -533,6 +535,7 @@ extern "C" int gpf_set_dt(gpf_handle* h, double dt) {
     StepState s;
     GPF_TRY(read_state(h, s));
     s.dt = dt;
+    h->g1_ready = false;
     return write_state(h, s);
 }
 
@@ -559,6 +562,7 @@ extern "C" int gpf_pre_run(gpf_handle* h) {
     s.dt = c.adaptive ? c.CFL * dt_crit : c.dt_fixed;
     GPF_TRY(write_state(h, s));
     h->pre_run_done = true;
+    h->g1_ready = false;
     h->host_step = 0; h->next_step = 0;
     return GPF_OK;
 }
@@ -665,26 +669,32 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     // Three launches per step:
     //   k_ghost_stage1  stage-1 values on the downwind ghost row / column (needs the dt the previous step committed)
     //   k_step          the fused predictor + corrector + average over the interior
+    //   (k_begin_p2p    peer-to-peer slabs only: wait for the peers' rows and records, commit, and do k_ghost_stage1's
+    //                   job for the next step in the same launch)
     //   k_ghost_fill    ghost cells of the new field (+ a slab's boundary rows into its message / its peers'
     //                   mailboxes); its last block to finish reduces all records and commits dt, residual, step
     const int gmax = std::max(L.Nx, L.Ny);
     const dim3 ggrid((gmax + 255) / 256, 2), sgrid((h->nstrips + 3) / 4, h->nchunks);
     const step_kernel_t kstep = step_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, D, topo_mode_of(h));
     const int nsend = slab ? (6 * L.pitch + 1023) / 1024 : 0;
+    WaitArgs w;
+    w.qa = h->q[0]; w.qb = h->q[1]; w.st = h->st; w.log = h->log; w.log_base = log_base; w.log_cap = h->log_cap;
+    w.L = L; w.E = h->E; w.honor_stop = honor_stop; w.arrive = h->arrive + 1; w.p2p = f.p2p;
     EOS_DISPATCH(h->cfg.eos, {
-        if (h->Ls) hipLaunchKernelGGL((k_ghost_stage1<EOS_, true>), ggrid, dim3(256), 0, h->stream, g, h->P);
-        else hipLaunchKernelGGL((k_ghost_stage1<EOS_, false>), ggrid, dim3(256), 0, h->stream, g, h->P);
+        if (!(p2p && h->g1_ready)) {        // (peer-to-peer: the previous step's k_begin_p2p has already done this)
+            if (h->Ls) hipLaunchKernelGGL((k_ghost_stage1<EOS_, true>), ggrid, dim3(256), 0, h->stream, g, h->P);
+            else hipLaunchKernelGGL((k_ghost_stage1<EOS_, false>), ggrid, dim3(256), 0, h->stream, g, h->P);
+        }
         if (ev0) hipEventRecord(ev0, h->stream);
         hipLaunchKernelGGL(kstep, sgrid, dim3(256), 0, h->stream, a, h->P);
         if (ev1) hipEventRecord(ev1, h->stream);
         hipLaunchKernelGGL((k_ghost_fill<EOS_>), dim3(h->nghost_blocks + nsend), dim3(256), 0, h->stream, gf, f, h->nghost_blocks, h->P);
+        if (p2p) {                          // wait for the peers, commit, stage-1 ghost data of the next step
+            if (h->Ls) hipLaunchKernelGGL((k_begin_p2p<EOS_, true>), ggrid, dim3(256), 0, h->stream, g, w, h->P);
+            else hipLaunchKernelGGL((k_begin_p2p<EOS_, false>), ggrid, dim3(256), 0, h->stream, g, w, h->P);
+        }
     });
-    if (p2p) {
-        WaitArgs w;
-        w.qa = h->q[0]; w.qb = h->q[1]; w.st = h->st; w.log = h->log; w.log_base = log_base; w.log_cap = h->log_cap;
-        w.L = L; w.E = h->E; w.honor_stop = honor_stop; w.p2p = f.p2p;
-        hipLaunchKernelGGL(k_wait_commit, dim3(1), dim3(1024), 0, h->stream, w);
-    }
+    h->g1_ready = p2p;
     HIP_TRY(hipGetLastError());
     return GPF_OK;
 }
@@ -1264,6 +1274,7 @@ extern "C" int gpf_open_step(gpf_handle* h) {
     hipLaunchKernelGGL(k_copy3, dim3(blocks_for(3 * L.plane)), dim3(256), 0, h->stream, h->q[s.parity], h->q[s.parity ^ 1], 3 * L.plane);
     HIP_TRY(hipGetLastError());
     h->step_open = true;
+    h->g1_ready = false;
     h->host_step = s.step; h->next_step = s.step;
     return GPF_OK;
 }

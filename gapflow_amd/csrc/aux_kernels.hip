@@ -149,6 +149,11 @@ __global__ __launch_bounds__(256) void k_scalars(const double* q, const double* 
 // ---------------------------------------------------------------------------------------------
 // commit: dt / residual / convergence bookkeeping (problem.py:565-586), one thread
 // ---------------------------------------------------------------------------------------------
+// dt_crit = min(dx, dy) / (v_max + v_sound)  (problem.py:354-356)
+__device__ __forceinline__ double critical_dt(const StepState* st, double v2, double c2) {
+    return st->hmin / (sqrt(v2) + sqrt(c2));
+}
+
 __device__ inline void commit_step(StepState* st, double ekin, double v2, double c2, int flags, LogEntry* log,
                                    long long log_base, long long log_cap) {
     if (flags & 4) c2 = __builtin_nan("");      // an imaginary sound speed somewhere: np.sqrt -> NaN -> max -> NaN
@@ -157,8 +162,7 @@ __device__ inline void commit_step(StepState* st, double ekin, double v2, double
         // invalid state: keep the pre-step field (parity not flipped) and stop (problem.py:588-610)
         st->invalid = (flags & 1) ? 1 : 2;
     } else {
-        const double vmax = sqrt(v2), vs = sqrt(c2);
-        const double dt_crit = st->hmin / (vmax + vs);
+        const double dt_crit = critical_dt(st, v2, c2);
         const double cfl = st->dt / dt_crit;
         const double res = fabs(ekin - st->ekin_old) / st->ekin_old / cfl;
         st->residual = res;
@@ -445,8 +449,12 @@ __global__ void k_halo_unpack(const HaloArgs a) {
     }
 }
 
-// Receiving side of the peer-to-peer transport: wait (bounded) for message seq+1 of every rank, scatter the two
-// neighbour rows into my outer rows, reduce the records in rank order and commit -- no host, no collective library.
+// Receiving side of the peer-to-peer transport, fused with the start of the NEXT step.  Every block waits (bounded)
+// for message seq+1 of every rank in this rank's own mailbox, works out what the commit will decide -- the same
+// rank-ordered reduction of the records, the same dt -- scatters its share of the two neighbour rows into the outer
+// rows and computes its share of the next step's stage-1 ghost values (reading the outer rows from the mailbox, since
+// other blocks are still scattering them).  The last block to arrive writes the committed state.  Nobody waits for
+// another block; no host, no collective library.
 constexpr int INVALID_PEER_TIMEOUT = 3;
 struct WaitArgs {
     double* qa; double* qb;
@@ -454,10 +462,12 @@ struct WaitArgs {
     LogEntry* log; long long log_base, log_cap;
     Layout L; Edges E;
     int honor_stop;
+    unsigned int* arrive;
     P2PArgs p2p;
 };
-__global__ __launch_bounds__(1024) void k_wait_commit(const WaitArgs a) {
-    __shared__ int missing;
+template <int EOS, bool HAS_LS>
+__global__ __launch_bounds__(256) void k_begin_p2p(const GhostArgs g, const WaitArgs a, const Phys P) {
+    __shared__ int missing, last;
     StepState* st = a.st;
     if (st->invalid != 0 || (a.honor_stop && (st->converged || st->step >= st->max_it))) return;
     const P2PArgs& c = a.p2p;
@@ -469,45 +479,64 @@ __global__ __launch_bounds__(1024) void k_wait_commit(const WaitArgs a) {
     if (threadIdx.x < c.nranks) {
         const long long t0 = wall_clock64();
         bool ok = false;
-        while (!ok && wall_clock64() - t0 < P2P_TIMEOUT_TICKS) {
+        int probes = 0;
+        for (;;) {
+            // relaxed while spinning (an acquire would invalidate the caches on every probe); fenced once below
             ok = __hip_atomic_load(&hd->flag[slot][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= n;
-            if (!ok) __builtin_amdgcn_s_sleep(2);
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((++probes & 255) == 0 && wall_clock64() - t0 > P2P_TIMEOUT_TICKS) break;
         }
         if (!ok) atomicAdd(&missing, 1);
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);    // once, after the flag has been seen (not on every probe)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     }
     __syncthreads();
     if (missing) {                      // a peer never delivered: stop this handle instead of spinning forever
-        if (threadIdx.x == 0) st->invalid = INVALID_PEER_TIMEOUT;
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) st->invalid = INVALID_PEER_TIMEOUT;
         return;
     }
+    // what the commit will decide (identical in every block and on every rank)
+    double ekin = 0.0, v2 = 0.0, c2 = 0.0;
+    int flags = 0;
+    for (int r = 0; r < c.nranks; ++r) {
+        const double* p = hd->rec[slot][r];
+        ekin += p[0];
+        v2 = fmax(v2, p[1]); c2 = fmax(c2, p[2]);
+        flags |= (int)p[3];
+    }
+    const double inf = __builtin_inf();
+    if (v2 == inf) v2 = __builtin_nan("");
+    if (c2 == inf) c2 = __builtin_nan("");
     const Layout& L = a.L;
-    double* q = st->parity ? a.qa : a.qb;
-    if (c.rank_lo >= 0 && a.E.halo[0]) {
-        const double* src = p2p_rows(c.box[c.rank], slot, 0, L.pitch);
-        for (int k = 0; k < 3; ++k)
-            for (int i = threadIdx.x; i < L.pitch; i += blockDim.x)
-                q[k * L.plane + i] = __builtin_nontemporal_load(src + k * L.pitch + i);
-    }
-    if (c.rank_hi >= 0 && a.E.halo[1]) {
-        const double* src = p2p_rows(c.box[c.rank], slot, 1, L.pitch);
-        for (int k = 0; k < 3; ++k)
-            for (int i = threadIdx.x; i < L.pitch; i += blockDim.x)
-                q[k * L.plane + (long long)(L.Nx + 1) * L.pitch + i] = __builtin_nontemporal_load(src + k * L.pitch + i);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double ekin = 0.0, v2 = 0.0, c2 = 0.0;
-        int flags = 0;
-        for (int r = 0; r < c.nranks; ++r) {
-            const double* p = hd->rec[slot][r];
-            ekin += p[0];
-            v2 = fmax(v2, p[1]); c2 = fmax(c2, p[2]);
-            flags |= (int)p[3];
+    const int nblocks = gridDim.x * gridDim.y, block = blockIdx.y * gridDim.x + blockIdx.x;
+    if ((flags & 3) == 0) {
+        double* q = st->parity ? a.qa : a.qb;           // the field the step has produced (current after the commit)
+        const double* row_lo = (c.rank_lo >= 0 && a.E.halo[0]) ? p2p_rows(c.box[c.rank], slot, 0, L.pitch) : nullptr;
+        const double* row_hi = (c.rank_hi >= 0 && a.E.halo[1]) ? p2p_rows(c.box[c.rank], slot, 1, L.pitch) : nullptr;
+        for (int t = block * blockDim.x + threadIdx.x; t < 6 * L.pitch; t += nblocks * blockDim.x) {
+            const int side = t / (3 * L.pitch), k = (t / L.pitch) % 3, i = t % L.pitch;
+            const double* src = side ? row_hi : row_lo;
+            if (src) q[k * L.plane + (long long)(side ? L.Nx + 1 : 0) * L.pitch + i] = src[k * L.pitch + i];
         }
-        const double inf = __builtin_inf();
-        if (v2 == inf) v2 = __builtin_nan("");
-        if (c2 == inf) c2 = __builtin_nan("");
+        // stage-1 ghost values of step+1 with the dt the commit is about to fix
+        const double c2_eff = (flags & 4) ? __builtin_nan("") : c2;
+        const double dt = st->adaptive ? st->CFL * critical_dt(st, v2, c2_eff) : st->dt;
+        const int D = direction_of_step(st, st->step + 1);
+        MailField fld;
+        fld.q = q; fld.L = L; fld.row_lo = row_lo; fld.row_hi = row_hi;
+        const int t = blockIdx.x * blockDim.x + threadIdx.x;
+        if (blockIdx.y == 0) {
+            if (t + 1 <= L.Ny) ghost_stage1_row<EOS, HAS_LS>(fld, g, P, D, t + 1, dt);
+        } else {
+            if (t + 1 <= L.Nx) ghost_stage1_col<EOS, HAS_LS>(fld, g, P, D, t + 1, dt);
+        }
+    }
+    // the last block to get here writes the committed state (the others have read everything they need from it)
+    __syncthreads();
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nblocks - 1 ? 1 : 0;
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *c.seq = n;
         commit_step(st, ekin, v2, c2, flags, a.log, a.log_base, a.log_cap);
     }

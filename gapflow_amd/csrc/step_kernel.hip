@@ -284,6 +284,18 @@ struct StoredField {
     const double* q; Layout L;
     __device__ __forceinline__ double get(int ix, int iy, int c) const { return q[c * L.plane + L.at(ix, iy)]; }
 };
+// A slab's field whose two outer rows are still in this rank's mailbox (peer-to-peer transport): what StoredField
+// will show once the rows have been scattered.
+struct MailField {
+    const double* q; Layout L;
+    const double* row_lo; const double* row_hi;     // [3][pitch] each, or nullptr: read the stored row
+    __device__ __forceinline__ double get(int ix, int iy, int c) const {
+        if (ix == 0 && row_lo) return row_lo[c * L.pitch + L.off + iy];
+        if (ix == L.Nx + 1 && row_hi) return row_hi[c * L.pitch + L.off + iy];
+        return q[c * L.plane + L.at(ix, iy)];
+    }
+};
+
 template <int EOS, bool HAS_LS, class Field>
 __device__ __forceinline__ void stage1_rate(const Field& fld, const GhostArgs& a, const Phys& P, int D, int ix, int iy,
                                             const double* tsrc, const double* tup, const double* lsrc, const double* lup,
@@ -319,7 +331,7 @@ __device__ __forceinline__ void stage1_rate(const Field& fld, const GhostArgs& a
 
 // one interior column iy of the downwind ghost ROW
 template <int EOS, bool HAS_LS, class Field>
-__device__ __forceinline__ void ghost_stage1_row(const Field& fld, const GhostArgs& a, const Phys& P, int D, int iy) {
+__device__ __forceinline__ void ghost_stage1_row(const Field& fld, const GhostArgs& a, const Phys& P, int D, int iy, double dt) {
     const Layout& L = a.L;
     const int edge = D > 0 ? 1 : 0;
     if (a.E.halo[edge] == 1) return;           // a neighbour's real cell: the stencil computes it
@@ -342,19 +354,19 @@ __device__ __forceinline__ void ghost_stage1_row(const Field& fld, const GhostAr
     }
     double A[3], R[3];
     stage1_rate<EOS, HAS_LS>(fld, a, P, D, ix_src, iy, ts, tu, ls, lu, ix_up, A, R);
-    for (int c = 0; c < 3; ++c) a.g1x[c * L.pitch + L.off + iy] = ghost_rule(a.E, edge, c, A[c] - a.st->dt * R[c]);
+    for (int c = 0; c < 3; ++c) a.g1x[c * L.pitch + L.off + iy] = ghost_rule(a.E, edge, c, A[c] - dt * R[c]);
 }
 
 // one interior row ix of the downwind ghost COLUMN
 template <int EOS, bool HAS_LS, class Field>
-__device__ __forceinline__ void ghost_stage1_col(const Field& fld, const GhostArgs& a, const Phys& P, int D, int ix) {
+__device__ __forceinline__ void ghost_stage1_col(const Field& fld, const GhostArgs& a, const Phys& P, int D, int ix, double dt) {
     const Layout& L = a.L;
     const int edge = D > 0 ? 3 : 2;
     const bool periodic = a.E.rule[edge][0] == BC_P;
     const int iy_src = periodic ? (D > 0 ? 1 : L.Ny) : (D > 0 ? L.Ny : 1);
     double A[3], R[3];
     stage1_rate<EOS, HAS_LS>(fld, a, P, D, ix, iy_src, nullptr, nullptr, nullptr, nullptr, ix - D, A, R);
-    for (int c = 0; c < 3; ++c) a.g1y[c * (L.Nx + 2) + ix] = ghost_rule(a.E, edge, c, A[c] - a.st->dt * R[c]);
+    for (int c = 0; c < 3; ++c) a.g1y[c * (L.Nx + 2) + ix] = ghost_rule(a.E, edge, c, A[c] - dt * R[c]);
 }
 
 // stage-1 ghost data of the step about to run, from the stored field (ghost cells and halo rows included)
@@ -365,11 +377,12 @@ __global__ __launch_bounds__(256) void k_ghost_stage1(const GhostArgs a, const P
     StoredField fld;
     fld.q = a.st->parity ? a.qb : a.qa; fld.L = L;
     const int D = predictor_direction(a.st);
+    const double dt = a.st->dt;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.y == 0) {
-        if (t + 1 <= L.Ny) ghost_stage1_row<EOS, HAS_LS>(fld, a, P, D, t + 1);
+        if (t + 1 <= L.Ny) ghost_stage1_row<EOS, HAS_LS>(fld, a, P, D, t + 1, dt);
     } else {
-        if (t + 1 <= L.Nx) ghost_stage1_col<EOS, HAS_LS>(fld, a, P, D, t + 1);
+        if (t + 1 <= L.Nx) ghost_stage1_col<EOS, HAS_LS>(fld, a, P, D, t + 1, dt);
     }
 }
 
