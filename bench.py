@@ -231,6 +231,23 @@ def run_slabs(args, rank, world):
             _emit(best)
         os._exit(0)
 
+    # ... and a GPU fault inside an attempt aborts the process from a runtime thread (SIGABRT): the measurement that
+    # already exists must not die with it.  libc-level handler; the callback only writes the prepared line and exits.
+    import ctypes
+    import signal
+
+    @ctypes.CFUNCTYPE(None, ctypes.c_int)
+    def on_fatal(signum):
+        if rank == 0:
+            _emit(best)
+        os._exit(0)
+    _keep_alive.append(on_fatal)
+    libc = ctypes.CDLL(None)
+    libc.signal.restype = ctypes.c_void_p
+    libc.signal.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    for sig in (signal.SIGABRT, signal.SIGSEGV, signal.SIGBUS):
+        libc.signal(int(sig), ctypes.cast(on_fatal, ctypes.c_void_p))
+
     def same_run(s2, steps):
         ok = (int(s2.step) == steps and s2.invalid == 0 and abs(s2.dt - st_ref[1]) <= 1e-12 * st_ref[1]
               and abs(s2.ekin - st_ref[2]) <= 1e-10 * st_ref[2])
@@ -288,12 +305,15 @@ def run_slabs(args, rank, world):
         attempt("peer-to-peer transport", try_p2p)
     if os.environ.get('GPF_BENCH_TRY_GRAPH', '1') == '1':
         attempt("graph replay", try_graph)
+    for sig in (signal.SIGABRT, signal.SIGSEGV, signal.SIGBUS):
+        libc.signal(int(sig), None)                         # SIG_DFL again
     dist.barrier()
     dist.destroy_process_group()
     return best if rank == 0 else None
 
 
 _emit = lambda obj: print(json.dumps(obj), flush=True)
+_keep_alive = []
 
 
 def main():
