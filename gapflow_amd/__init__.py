@@ -11,3 +11,4 @@ include/gapflow_hip.h); there is no CPU fallback.
 __version__ = "0.1.0"
 
 from .problem import Problem  # noqa: E402,F401
+from .gp import Database  # noqa: E402,F401  (GaPFlow/__init__.py:36)

@@ -38,11 +38,14 @@ SQRT3 = np.sqrt(3.0)
 def neg_log_likelihood(theta, X, Y, sigma):
     """Value and gradient w.r.t. theta = [log_amp, log_scale_1..d] (gp.py:307-318, 598-603)."""
     n, m = Y.shape
-    amp, inv_scale = np.exp(theta[0]), np.exp(-theta[1:])
-    sd = (X[:, None, :] - X[None, :, :]) * inv_scale
-    r = np.sqrt(np.sum(sd * sd, axis=-1))
-    E = np.exp(-SQRT3 * r)
-    Kf = amp * (1.0 + SQRT3 * r) * E
+    with np.errstate(all='ignore'):
+        amp, inv_scale = np.exp(theta[0]), np.exp(-theta[1:])
+        sd = (X[:, None, :] - X[None, :, :]) * inv_scale
+        r = np.sqrt(np.sum(sd * sd, axis=-1))
+        E = np.exp(-SQRT3 * r)
+        Kf = amp * (1.0 + SQRT3 * r) * E
+    if not np.all(np.isfinite(Kf)):     # a line-search probe far outside the sensible range: reject the step
+        return 1e300, np.zeros_like(theta)
     try:
         c = cho_factor(Kf + sigma**2 * np.eye(n), lower=True)
     except np.linalg.LinAlgError:
@@ -225,6 +228,14 @@ class Surrogate:
         self.history = {k: [] for k in ('step', 'database_size', 'variance', 'obs_stddev', 'maximum_variance', 'variance_tol')}
         for li in self.active_dims:
             self.history[f'lengthscale_{li}'] = []
+
+    def __repr__(self):
+        # the reference dumps the tinygp object here (problem.py:492); the same facts in plain text
+        ls = ', '.join(f'{v:.6g}' for v in self.kernel_lengthscale) if self.theta is not None else '-'
+        var = f'{self.kernel_variance:.6g}' if self.theta is not None else '-'
+        return (f"GaussianProcess(kernel=Matern32, name={self.name}, active_dims={self.active_dims}, "
+                f"n_train={self.last_fit_train_size}, variance={var}, lengthscales=[{ls}], "
+                f"obs_stddev={self.obs_stddev if self.last_fit_train_size else '-'})")
 
     # -- training data views (stress.py:199-258, 546-569) ----------------------------------
     @property

@@ -454,9 +454,18 @@ class Problem:
         print(33 * '=')
         print("Total walltime   : ", str(walltime).split('.')[0])
         print(f"({speed:.2f} steps/s)")
+        for name in ('zz', 'xz', 'yz'):             # problem.py:475-483
+            m = self._gp_models.get(name)
+            if m is not None:
+                print(f" - GP train ({name}) : ", str(m.cumtime_train).split('.')[0])
+                print(f" - GP infer ({name}) : ", str(m.cumtime_infer).split('.')[0])
         print(33 * '=')
         if not silent:
             history_to_csv(os.path.join(self.outdir, 'history.csv'), self.history)
+            for name, m in self._gp_models.items():  # problem.py:490-503
+                history_to_csv(os.path.join(self.outdir, f'gp_{name}.csv'), m.history)
+                with open(os.path.join(self.outdir, f'gp_{name}.txt'), 'w') as f:
+                    print(m, file=f)
 
     def write(self, scalars=True, fields=True, params=True):
         # problem.py:616-637

@@ -75,12 +75,15 @@ def neg_log_likelihood(theta, X, Y, sigma):
     X = np.asarray(X, float)
     Y = np.asarray(Y, float).reshape(len(X), -1)
     n, m = Y.shape
-    amp, inv_scale = np.exp(theta[0]), np.exp(-theta[1:])
-    diff = X[:, None, :] - X[None, :, :]
-    sd = diff * inv_scale
-    r = np.sqrt(np.sum(sd * sd, axis=-1))
-    E = np.exp(-SQRT3 * r)
-    Kf = amp * (1.0 + SQRT3 * r) * E
+    with np.errstate(all='ignore'):
+        amp, inv_scale = np.exp(theta[0]), np.exp(-theta[1:])
+        diff = X[:, None, :] - X[None, :, :]
+        sd = diff * inv_scale
+        r = np.sqrt(np.sum(sd * sd, axis=-1))
+        E = np.exp(-SQRT3 * r)
+        Kf = amp * (1.0 + SQRT3 * r) * E
+    if not np.all(np.isfinite(Kf)):     # a line-search probe far outside the sensible range: reject the step
+        return 1e300, np.zeros_like(theta)
     K = Kf + sigma**2 * np.eye(n)
     try:
         c = cho_factor(K, lower=True)

@@ -168,3 +168,19 @@ properties: {shear: 0.1, bulk: 0., EOS: DH}
     a = (ctypes.c_double * 48)()
     assert lib.gpf_predictor_corrector(4, 4, a, a, a, 1, a, a) == -3       # GPF_ERR_NO_DEVICE
     assert b'no HIP device' in lib.gpf_last_error()
+
+
+def test_reference_module_paths_exist():
+    """A script written against the reference imports these paths (examples/slip_1d_lj_mock.py:5-8,
+    GaPFlow/__init__.py:36-37, models/__init__.py:24-26); LAMMPS runners are refused by name."""
+    import gapflow_amd
+    from gapflow_amd.problem import Problem
+    from gapflow_amd.io import read_yaml_input  # noqa: F401
+    from gapflow_amd.db import Database
+    from gapflow_amd.md import Mock  # noqa: F401
+    from gapflow_amd.models import Pressure, WallStress, BulkStress  # noqa: F401
+    from gapflow_amd.integrate import predictor_corrector, source  # noqa: F401
+    assert gapflow_amd.Problem is Problem and gapflow_amd.Database is Database
+    import gapflow_amd.md as md
+    with pytest.raises(NotImplementedError):
+        md.LennardJones
