@@ -15,6 +15,11 @@ EOS_IDS = {'DH': 0, 'PL': 1, 'vdW': 2, 'MT': 3, 'cubic': 4, 'BWR': 5, 'Bayada': 
 EOS_KEYS = {'DH': ['rho0', 'P0', 'C1', 'C2'], 'PL': ['rho0', 'P0', 'alpha'], 'vdW': ['M', 'T', 'a', 'b'],
             'MT': ['rho0', 'P0', 'K', 'n'], 'cubic': ['a', 'b', 'c', 'd'], 'BWR': ['T', 'gamma'],
             'Bayada': ['rho_l', 'rho_v', 'c_l', 'c_v']}
+# defaults of the reference's EOS functions (pressure.py:79, 112, 140, 176, 208, 233): eos_pressure passes only the keys
+# present in `properties` (pressure.py:73-76), so absent ones take these
+EOS_DEFAULTS = {'DH': {'rho0': 877.7007, 'P0': 101325., 'C1': 3.5e8, 'C2': 1.23}, 'PL': {'rho0': 1.1853, 'P0': 101325., 'alpha': 0.},
+                'vdW': {'M': 39.948, 'T': 100., 'a': 1.355, 'b': 0.03201}, 'MT': {'rho0': 700., 'P0': 0.101e6, 'K': 0.557e9, 'n': 7.33},
+                'cubic': {'a': 15.2, 'b': -9.6, 'c': 3.35, 'd': -0.07}, 'BWR': {'gamma': 3.}, 'Bayada': {}}
 PIEZO_IDS = {'Barus': 1, 'Roelands': 2, 'Dukler': 3, 'McAdams': 4}
 PIEZO_KEYS = {'Barus': ['aB'], 'Roelands': ['mu_inf', 'p_ref', 'z'], 'Dukler': ['eta_v', 'rho_l', 'rho_v'],
               'McAdams': ['eta_v', 'rho_l', 'rho_v']}

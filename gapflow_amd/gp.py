@@ -20,6 +20,7 @@ NumPy's default_rng with the same seeds is used instead.
 import contextlib
 import ctypes as C
 import io as _io
+import os
 from datetime import datetime
 
 import numpy as np
@@ -78,6 +79,46 @@ class Mock:
         self.prop, self.geo = prop, geo
         self.params = dict(prop)
         self._eval = None
+        self._dtool_basepath = None     # set by Database.set_training_path; None: keep runs in memory only
+
+    dtool_basepath = property(lambda self: self._dtool_basepath)
+
+    def _write_dataset(self, X, Y, Ye, tag):
+        """One directory per run with the run's inputs and outputs in README.yml, as md/base.py:128-188 leaves them
+        (name, README keys X / Y / Yerr / parameters / owners / dates).  The `.dtool` administrative files follow the
+        dtool on-disk layout as far as it is known here without dtoolcore (absent offline, so unverified against it);
+        this package itself only needs README.yml to reload a database."""
+        import getpass
+        import json
+        import uuid
+        import yaml
+        from datetime import date
+        now = datetime.now()
+        name = f'{now.strftime("%Y%m%d_%H%M%S")}_{self.name}-{int(tag):03}'
+        root = os.path.join(self._dtool_basepath, name)
+        k = 0
+        while os.path.exists(root):         # two runs within the same second and tag
+            k += 1
+            root = os.path.join(self._dtool_basepath, f'{name}_{k}')
+        os.makedirs(os.path.join(root, 'data'))
+        os.makedirs(os.path.join(root, '.dtool'))
+        today = date.today()
+        try:
+            expires = today.replace(year=today.year + 10)
+        except ValueError:                  # 29 February
+            expires = today.replace(year=today.year + 10, day=28)
+        plain = lambda a: [float(v) for v in np.asarray(a, float).ravel()]
+        readme = {'owners': [{'username': getpass.getuser()}], 'creation_date': today, 'expiration_date': expires,
+                  'parameters': {k_: (v if isinstance(v, (int, float, str, bool, dict, list)) else str(v)) for k_, v in self.params.items()},
+                  'X': plain(X), 'Y': plain(Y), 'Yerr': plain(Ye)}
+        with open(os.path.join(root, 'README.yml'), 'w') as f:
+            yaml.safe_dump(readme, f)
+        admin = {'uuid': str(uuid.uuid4()), 'dtoolcore_version': '3.18.2', 'name': os.path.basename(root), 'type': 'dataset',
+                 'creator_username': getpass.getuser(), 'created_at': now.timestamp(), 'frozen_at': datetime.now().timestamp()}
+        with open(os.path.join(root, '.dtool', 'dtool'), 'w') as f:
+            json.dump(admin, f)
+        with open(os.path.join(root, '.dtool', 'manifest.json'), 'w') as f:
+            json.dump({'dtoolcore_version': admin['dtoolcore_version'], 'hash_function': 'md5sum_hexdigest', 'items': {}}, f)
 
     def _evaluator(self):
         if self._eval is None:
@@ -89,6 +130,8 @@ class Mock:
             numerics = {'tol': 1e-6, 'max_it': 1, 'dt': 1e-12, 'adaptive': False, 'CFL': 0.5, 'MC_order': 1}
             prop = {k: v for k, v in self.prop.items() if k not in ('piezo', 'thinning')}
             prop.setdefault('elastic', {'enabled': False})
+            # absent rho0: the EOS function's own default (pressure.py:73-76); it also seeds the evaluator's initial state
+            prop.setdefault('rho0', _lib.EOS_DEFAULTS.get(prop['EOS'], {}).get('rho0', 1.0))
             self._eval = Problem({'output': '', 'write_freq': 1, 'use_tstamp': False, 'silent': True}, grid, numerics,
                                  prop, geo, device=self.device)
         return self._eval
@@ -111,11 +154,15 @@ class Mock:
         Y = np.concatenate([[p + noise_p], bot + noise_s0, top + noise_s1])
         s = self.noise[1]
         Ye = np.array([self.noise[0], 0., 0., 0., s, s, 0., 0., 0., 0., s, s, 0.])
+        if self._dtool_basepath is not None:
+            self._write_dataset(X, Y, Ye, 0 if tag is None else tag)
         return Y, Ye
 
 
 class Database:
-    """Training data of all surrogates (db.py:46-369), in memory."""
+    """Training data of all surrogates (db.py:46-369).  With a `dtool_path` every run is also kept as a dataset
+    directory below it and an existing directory is loaded on construction (db.py:79-103); without one the database
+    lives in memory until a Problem gives it `<output>/train` (problem.py:158-161)."""
 
     def __init__(self, md, db, num_extra_features=1):
         self._md, self._db = md, db
@@ -126,6 +173,40 @@ class Database:
         self._X_scale = np.ones(self._num_features)
         self._Y_scale = np.ones(13)
         self.output_path = None
+        self._training_path = None
+        self._temporary_training_path = True
+        path = db.get('dtool_path')
+        if path is not None:
+            self._temporary_training_path = False
+            self.set_training_path(path)
+            readmes = self.get_readme_list_local()
+            if readmes:
+                self.set_arrays([r['X'] for r in readmes], [r['Y'] for r in readmes], [r['Yerr'] for r in readmes])
+
+    training_path = property(lambda self: self._training_path)
+
+    def set_training_path(self, new_path, check_temporary=False):
+        """db.py:236-262: where new runs are stored (also tells the MD runner)."""
+        if check_temporary and not self._temporary_training_path:
+            return
+        os.makedirs(new_path, exist_ok=True)
+        self._training_path = new_path
+        self._md._dtool_basepath = new_path
+        self._db['dtool_path'] = new_path
+
+    def get_readme_list_local(self):
+        """README.yml contents of the datasets below the training path, oldest first (db.py:193-209)."""
+        import yaml
+        out = []
+        for name in sorted(os.listdir(self._training_path)):
+            fn = os.path.join(self._training_path, name, 'README.yml')
+            if os.path.isfile(fn):
+                with open(fn) as f:
+                    rm = yaml.safe_load(f)
+                if isinstance(rm, dict) and all(k in rm for k in ('X', 'Y', 'Yerr')):
+                    out.append(rm)
+        print(f"Loading {len(out)} local datasets in '{self._training_path}'.")
+        return out
 
     config = property(lambda self: self._db)
     md_config = property(lambda self: self._md.params)

@@ -93,9 +93,15 @@ class Problem:
 
         if not options['silent']:
             self.outdir = create_output_directory(options['output'], options['use_tstamp'])
+            if database is not None:            # problem.py:158-164: MD datasets go below the run's output directory
+                database.set_training_path(os.path.join(self.outdir, 'train'), check_temporary=True)
+                database.output_path = self.outdir
+                options['output'] = self.outdir
             full = {'version': __version__}
             for k, v in zip(['options', 'grid', 'numerics', 'geo', 'prop'], [options, grid, numerics, geo, prop]):
                 full[k] = v
+            if database is not None:            # problem.py:175-178
+                full['gp'], full['db'], full['md'] = gp, database.config, database.md_config
             write_yaml(full, os.path.join(self.outdir, 'config.yml'))
             from .output import FieldWriter
             self._writer = FieldWriter(self)
@@ -175,7 +181,9 @@ class Problem:
             raise NotImplementedError(f"EOS '{p['EOS']}' needs a surrogate model (gp/db sections)")
         cfg.eos = _lib.EOS_IDS[p['EOS']]
         for i, k in enumerate(_lib.EOS_KEYS[p['EOS']]):
-            cfg.eos_par[i] = p[k]
+            if k not in p and k not in _lib.EOS_DEFAULTS[p['EOS']]:
+                raise TypeError(f"EOS '{p['EOS']}' needs the property '{k}'")
+            cfg.eos_par[i] = p.get(k, _lib.EOS_DEFAULTS[p['EOS']].get(k))
         cfg.piezo = 0
         if 'piezo' in p and p['piezo']['name'] in _lib.PIEZO_IDS:
             name = p['piezo']['name']

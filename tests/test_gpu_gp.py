@@ -177,3 +177,31 @@ db: {init_size: 3, init_method: rand, init_width: 0.01}
     assert np.isfinite(prob.q).all() and (prob.q[0] > 0).all()
     for m in prob._gp_models.values():
         assert m.last_fit_train_size == prob.database.size or m._pause >= 0
+
+
+@pytest.mark.parametrize('method', ['rand', 'lhc', 'sobol'])
+def test_database_addition_and_reload(hiplib, tmp_path, method):
+    """tests/test_database.py:30-55 of the reference: initialise, add, and find everything again through a second
+    Database on the same dtool_path."""
+    from gapflow_amd import Database
+    from gapflow_amd.md import Mock
+    db_config = {'init_size': 4, 'init_width': 0.01, 'init_method': method, 'init_seed': 42, 'dtool_path': str(tmp_path)}
+    geo = {'U': 1., 'V': 0.}
+    prop = {'shear': 1., 'bulk': 0., 'EOS': 'PL'}
+    gp = {'press_gp': False, 'shear_gp': False}
+    md = Mock(prop, geo, gp)
+    db = Database(md, db_config, num_extra_features=1)
+    Xtest = np.random.default_rng(0).uniform(0.1, 1., size=(100, 7))
+    db.initialize(Xtest)
+    assert db.size == db_config['init_size']
+    Xnew = np.random.default_rng(1).uniform(0.1, 1., size=(10, 7))
+    db.add_data(Xnew)
+    assert db.size == 14
+    new_db = Database(md, db_config, num_extra_features=1)
+    assert new_db.size == 14
+    np.testing.assert_allclose(np.sort(new_db._Xtrain, axis=0), np.sort(db._Xtrain, axis=0), rtol=1e-15)
+    np.testing.assert_allclose(np.sort(new_db._Ytrain, axis=0), np.sort(db._Ytrain, axis=0), rtol=1e-15)
+    # Mock semantics (md/mock.py:92-96): PL pressure with the function's defaults, noise-free here
+    from oracle import closures as ocl
+    p_ref = ocl.eos_pressure(db._Xtrain[:, 0], {'EOS': 'PL', 'rho0': 1.1853, 'P0': 101325., 'alpha': 0.})
+    np.testing.assert_allclose(db._Ytrain[:, 0], p_ref, rtol=1e-12)
