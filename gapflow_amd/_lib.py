@@ -73,6 +73,8 @@ SIGNATURES = {
     'gpf_step_local': (C.c_int, [C.c_void_p, C.c_int]),
     'gpf_step_commit': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     'gpf_state': (C.c_int, [C.c_void_p, C.POINTER(GpfScalars)]),
+    'gpf_viscous_stress': (C.c_int, [C.c_int64] + [C.c_void_p] * 6 + [C.c_double] * 3 + [C.c_int] + [C.c_void_p] * 3),
+    'gpf_eos': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     'gpf_p2p_export': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     'gpf_p2p_connect': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     'gpf_step_p2p': (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),

@@ -848,6 +848,81 @@ extern "C" int gpf_source(int nx, int ny, const double* q, const double* hh, con
     return rc;
 }
 
+// models/viscous.py as functions of arrays: stress_bottom / stress_top / stress_avg in one call
+extern "C" int gpf_viscous_stress(int64_t n, const double* q, const double* hh, const double* dqx, const double* dqy,
+                                  const double* eta, const double* Ls, double U, double V, double zeta, int slip_both,
+                                  double* bottom, double* top, double* avg) {
+    if (!q || !hh || !eta || !Ls) return fail(GPF_ERR_INVALID, "gpf_viscous_stress: null argument");
+    if (!bottom && !top && !avg) return fail(GPF_ERR_INVALID, "gpf_viscous_stress: no output requested");
+    if (n < 1) return fail(GPF_ERR_INVALID, "gpf_viscous_stress: n >= 1 required");
+    if (gpf_device_count() == 0) return fail(GPF_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    const size_t N = (size_t)n;
+    double* d = nullptr;
+    HIP_TRY(hipMalloc(&d, 29 * N * sizeof(double)));
+    ViscousArgs a;
+    double* w = d;
+    auto put = [&](const double* host, size_t count, const double** dev) -> hipError_t {
+        *dev = nullptr;
+        if (!host) return hipSuccess;
+        *dev = w;
+        hipError_t e = hipMemcpy(w, host, count * sizeof(double), hipMemcpyHostToDevice);
+        w += count;
+        return e;
+    };
+    hipError_t e;
+    int rc = GPF_OK;
+    if ((e = put(q, 3 * N, &a.q)) != hipSuccess || (e = put(hh, 3 * N, &a.h)) != hipSuccess ||
+        (e = put(dqx, 3 * N, &a.dqx)) != hipSuccess || (e = put(dqy, 3 * N, &a.dqy)) != hipSuccess ||
+        (e = put(eta, N, &a.eta)) != hipSuccess || (e = put(Ls, N, &a.Ls)) != hipSuccess) {
+        rc = fail(GPF_ERR_HIP, hipGetErrorString(e));
+    } else {
+        a.U = U; a.V = V; a.zeta = zeta; a.slip_both = slip_both ? 1 : 0; a.n = n;
+        a.out[0] = bottom ? w : nullptr; if (bottom) w += 6 * N;
+        a.out[1] = top ? w : nullptr; if (top) w += 6 * N;
+        a.out[2] = avg ? w : nullptr;
+        hipLaunchKernelGGL(k_viscous, dim3(blocks_for((long long)n)), dim3(256), 0, 0, a);
+        if ((e = hipGetLastError()) != hipSuccess ||
+            (bottom && (e = hipMemcpy(bottom, a.out[0], 6 * N * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) ||
+            (top && (e = hipMemcpy(top, a.out[1], 6 * N * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) ||
+            (avg && (e = hipMemcpy(avg, a.out[2], 3 * N * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess))
+            rc = fail(GPF_ERR_HIP, hipGetErrorString(e));
+    }
+    hipFree(d);
+    return rc;
+}
+
+// models/pressure.py eos_pressure and models/sound.py eos_sound_velocity as functions of an array
+extern "C" int gpf_eos(int eos, const double* eos_par, int64_t n, const double* rho, double* pressure, double* sound) {
+    if (!eos_par || !rho || (!pressure && !sound)) return fail(GPF_ERR_INVALID, "gpf_eos: null argument");
+    if (eos < 0 || eos > GPF_EOS_BAYADA) return fail(GPF_ERR_INVALID, "gpf_eos: unknown equation of state");
+    if (n < 1) return fail(GPF_ERR_INVALID, "gpf_eos: n >= 1 required");
+    if (gpf_device_count() == 0) return fail(GPF_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    gpf_config c;
+    std::memset(&c, 0, sizeof(c));
+    c.eos = eos; c.dx = c.dy = 1.0;
+    for (int i = 0; i < 8; ++i) c.eos_par[i] = eos_par[i];
+    Phys P;
+    make_phys(c, P);
+    const size_t N = (size_t)n;
+    double* d = nullptr;
+    HIP_TRY(hipMalloc(&d, 3 * N * sizeof(double)));
+    hipError_t e;
+    int rc = GPF_OK;
+    if ((e = hipMemcpy(d, rho, N * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) {
+        rc = fail(GPF_ERR_HIP, hipGetErrorString(e));
+    } else {
+        double* dp = pressure ? d + N : nullptr;
+        double* dc = sound ? d + 2 * N : nullptr;
+        EOS_DISPATCH(eos, { hipLaunchKernelGGL((k_eos<EOS_>), dim3(blocks_for((long long)n)), dim3(256), 0, 0, d, (long long)n, P, dp, dc); });
+        if ((e = hipGetLastError()) != hipSuccess ||
+            (pressure && (e = hipMemcpy(pressure, dp, N * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) ||
+            (sound && (e = hipMemcpy(sound, dc, N * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess))
+            rc = fail(GPF_ERR_HIP, hipGetErrorString(e));
+    }
+    hipFree(d);
+    return rc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // slab decomposition
 // ---------------------------------------------------------------------------------------------

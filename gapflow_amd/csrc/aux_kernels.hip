@@ -719,4 +719,45 @@ __global__ void k_commit_unfused(StepState* st, const ScalarPartial* pre_bc, con
     commit_step(st, post_bc->ekin, post_bc->v2, post_bc->c2, flags, nullptr, 0, 0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// stateless closure operators (GaPFlow/models/viscous.py, pressure.py, sound.py as functions)
+// ---------------------------------------------------------------------------------------------
+struct ViscousArgs {
+    const double* q; const double* h; const double* dqx; const double* dqy;     // [3][n] each; dq* may be null (= 0)
+    const double* eta; const double* Ls;                                        // [n]
+    double U, V, zeta;
+    int slip_both;              // 0: only the upper wall slips (viscous.py's first branch); 1: both walls
+    double* out[3];             // lower wall [6][n], upper wall [6][n], gap average [3][n]; any may be null
+    long long n;
+};
+__global__ __launch_bounds__(256) void k_viscous(const ViscousArgs a) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < a.n; i += (long long)gridDim.x * blockDim.x) {
+        double q[3], h[3], dx[3] = {0.0, 0.0, 0.0}, dy[3] = {0.0, 0.0, 0.0};
+        for (int c = 0; c < 3; ++c) {
+            q[c] = a.q[c * a.n + i]; h[c] = a.h[c * a.n + i];
+            if (a.dqx) dx[c] = a.dqx[c * a.n + i];
+            if (a.dqy) dy[c] = a.dqy[c * a.n + i];
+        }
+        const double Ls = a.Ls[i], lo = a.slip_both ? Ls : 0.0;
+        for (int w = 0; w < 3; ++w) {
+            if (!a.out[w]) continue;
+            double t[6];
+            viscous_general(w, q, h, dx, dy, a.U, a.V, a.eta[i], a.zeta, lo, Ls, t);
+            if (w < 2) {
+                for (int c = 0; c < 6; ++c) a.out[w][c * a.n + i] = t[c];
+            } else {
+                a.out[2][i] = t[0]; a.out[2][a.n + i] = t[1]; a.out[2][2 * a.n + i] = t[5];     // xx, yy, xy (viscous.py:612)
+            }
+        }
+    }
+}
+
+template <int EOS>
+__global__ __launch_bounds__(256) void k_eos(const double* rho, long long n, Phys P, double* p, double* c) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        if (p) p[i] = eos_pressure<EOS>(rho[i], P);
+        if (c) c[i] = sqrt(eos_c2<EOS>(rho[i], P));
+    }
+}
+
 }  // namespace gpf

@@ -66,6 +66,64 @@ GPF_HD double rcp(double x) {
 #endif
 }
 
+// ---- viscous stresses of the general slip model (stateless operator gpf_viscous_stress) ----------------------
+// The in-plane velocity across the gap is the parabola u(z) = a z^2 + b z + c fixed by
+//     u(0) = W + lo u'(0)      lower wall moving with W, Navier slip length lo
+//     u(h) = -hi u'(h)         upper wall at rest, slip length hi
+//     1/h int_0^h u dz = m     m = j / rho, the gap-averaged velocity
+// (the model behind GaPFlow/models/viscous.py and profiles.py: slip="top" is lo = 0, hi = Ls; every other keyword
+// takes viscous.py's second branch, lo = hi = Ls).  With D = h^2 + 4 h (lo + hi) + 12 lo hi:
+//     a = [3 (h + 2 hi) W - 6 (h + lo + hi) m] / (h D),  b = [-4 (h + 3 hi) W + 6 (h + 2 hi) m] / D,
+//     c = [h (h + 4 hi) W + 6 lo (h + 2 hi) m] / D
+// The Newtonian stress needs du/dz = 2 a z + b and the in-plane derivatives at fixed z,
+//     du/dx = (a_h z^2 + b_h z + c_h) dh/dx + (a_m z^2 + b_m z + c_m) dm/dx,   dm/dx = (dj/dx - m drho/dx) / rho
+// evaluated at z = 0 (lower wall), z = h (upper wall) and averaged over the gap.
+struct Parabola { double a, b, c, ah, bh, ch, am, bm, cm; };
+
+GPF_HD Parabola slip_parabola(double h, double W, double m, double lo, double hi) {
+    const double D = h * h + 4.0 * h * (lo + hi) + 12.0 * lo * hi, Dh = 2.0 * h + 4.0 * (lo + hi);
+    const double iD = 1.0 / D, ihD = 1.0 / (h * D);
+    const double Na = 3.0 * (h + 2.0 * hi) * W - 6.0 * (h + lo + hi) * m;
+    const double Nb = -4.0 * (h + 3.0 * hi) * W + 6.0 * (h + 2.0 * hi) * m;
+    const double Nc = h * (h + 4.0 * hi) * W + 6.0 * lo * (h + 2.0 * hi) * m;
+    Parabola p;
+    p.a = Na * ihD; p.b = Nb * iD; p.c = Nc * iD;
+    p.ah = ((3.0 * W - 6.0 * m) * (h * D) - Na * (D + h * Dh)) * ihD * ihD;
+    p.bh = ((-4.0 * W + 6.0 * m) * D - Nb * Dh) * iD * iD;
+    p.ch = (((2.0 * h + 4.0 * hi) * W + 6.0 * lo * m) * D - Nc * Dh) * iD * iD;
+    p.am = -6.0 * (h + lo + hi) * ihD; p.bm = 6.0 * (h + 2.0 * hi) * iD; p.cm = 6.0 * lo * (h + 2.0 * hi) * iD;
+    if (lo == 0.0) { p.c = W; p.ch = 0.0; }     // u(0) = W exactly: no rounding residue in the lower wall's normal stresses
+    return p;
+}
+
+// where: 0 lower wall, 1 upper wall, 2 gap average.  out: xx, yy, zz, yz, xz, xy (Voigt order of viscous.py:85).
+GPF_HD void viscous_general(int where, const double q[3], const double hh[3], const double dqx[3], const double dqy[3],
+                            double U, double V, double eta, double zeta, double lo, double hi, double out[6]) {
+    const double h = hh[0], irho = 1.0 / q[0];
+    const double mu = q[1] * irho, mv = q[2] * irho;
+    const Parabola pu = slip_parabola(h, U, mu, lo, hi), pv = slip_parabola(h, V, mv, lo, hi);
+    // weights of (z^2, z, 1) at the requested place
+    const double w2 = where == 0 ? 0.0 : (where == 1 ? h * h : h * h / 3.0);
+    const double w1 = where == 0 ? 0.0 : (where == 1 ? h : 0.5 * h);
+    auto at = [&](double c2, double c1, double c0) { return c2 * w2 + c1 * w1 + c0; };
+    const double mux = (dqx[1] - mu * dqx[0]) * irho, muy = (dqy[1] - mu * dqy[0]) * irho;
+    const double mvx = (dqx[2] - mv * dqx[0]) * irho, mvy = (dqy[2] - mv * dqy[0]) * irho;
+    const double ux = at(pu.ah, pu.bh, pu.ch) * hh[1] + at(pu.am, pu.bm, pu.cm) * mux;
+    const double uy = at(pu.ah, pu.bh, pu.ch) * hh[2] + at(pu.am, pu.bm, pu.cm) * muy;
+    const double vx = at(pv.ah, pv.bh, pv.ch) * hh[1] + at(pv.am, pv.bm, pv.cm) * mvx;
+    const double vy = at(pv.ah, pv.bh, pv.ch) * hh[2] + at(pv.am, pv.bm, pv.cm) * mvy;
+    // du/dz = 2 a z + b: b at the lower wall, 2 a h + b at the upper one, a h + b on average
+    const double zf = where == 0 ? 0.0 : (where == 1 ? 2.0 * h : h);
+    const double uz = pu.a * zf + pu.b, vz = pv.a * zf + pv.b;
+    const double v1 = zeta + (4.0 / 3.0) * eta, v2 = zeta - (2.0 / 3.0) * eta;
+    out[0] = v1 * ux + v2 * vy;
+    out[1] = v2 * ux + v1 * vy;
+    out[2] = v2 * (ux + vy);
+    out[3] = eta * vz;
+    out[4] = eta * uz;
+    out[5] = eta * (uy + vx);
+}
+
 // ---- equations of state -------------------------------------------------------------------
 
 template <int EOS>

@@ -201,6 +201,19 @@ int gpf_predictor_corrector(int nx, int ny, const double* q, const double* p, co
 int gpf_source(int nx, int ny, const double* q, const double* h, const double* stress,
                const double* lower, const double* upper, double* out);
 
+/* ---- stateless operators: GaPFlow/models as functions of arrays ----------------------------------- */
+/* stress_bottom / stress_top / stress_avg (models/viscous.py:37, 281, 612) for n points in one call.  Arrays are
+ * component-major: q, hh (h, dh/dx, dh/dy), dqx, dqy [3][n] (dqx, dqy may be NULL = zero gradients, the solver's
+ * case); eta, Ls [n] (viscosity and slip length per point).  slip_both = 0: slip="top" (only the upper wall slips,
+ * what the solver uses); 1: the other branch of viscous.py (both walls; Ls = 0 is no slip).  Outputs, any of which
+ * may be NULL: bottom, top [6][n] in Voigt order xx, yy, zz, yz, xz, xy; avg [3][n] = xx, yy, xy. */
+int gpf_viscous_stress(int64_t n, const double* q, const double* hh, const double* dqx, const double* dqy,
+                       const double* eta, const double* Ls, double U, double V, double zeta, int slip_both,
+                       double* bottom, double* top, double* avg);
+/* eos_pressure (models/pressure.py:35-76) and eos_sound_velocity (models/sound.py) of n densities; eos / eos_par as
+ * in gpf_config; either output may be NULL. */
+int gpf_eos(int eos, const double* eos_par, int64_t n, const double* rho, double* pressure, double* sound);
+
 /* ---- the unfused step in pieces ------------------------------------------------------------- */
 /* For closures that need the host between stages (GP surrogates with active learning, gp.py:435-506):
  * gpf_open_step copies q0; per stage gpf_stage_closures evaluates Pressure/WallStress/BulkStress on the

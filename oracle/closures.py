@@ -215,8 +215,58 @@ def shear_thinning_factor(shear_rate, mu0, th):
 # Viscous stresses (viscous.py), grad q == 0
 # ----------------------------------------------------------------------------
 
-def stress_bottom(q, h, U, V, eta, zeta, Ls, slip="top"):
+def _slip_parabola(h, W, m, lo, hi):
+    """u(z) = a z^2 + b z + c with u(0) = W + lo u'(0), u(h) = -hi u'(h), mean(u) = m; coefficients and their
+    partial derivatives with respect to h and m.  This is the velocity model behind viscous.py / profiles.py
+    (profiles.py:60-135 lists the resulting u(z) per slip keyword); derived here, not transcribed."""
+    D = h * h + 4 * h * (lo + hi) + 12 * lo * hi
+    Dh = 2 * h + 4 * (lo + hi)
+    Na = 3 * (h + 2 * hi) * W - 6 * (h + lo + hi) * m
+    Nb = -4 * (h + 3 * hi) * W + 6 * (h + 2 * hi) * m
+    Nc = h * (h + 4 * hi) * W + 6 * lo * (h + 2 * hi) * m
+    a, b, c = Na / (h * D), Nb / D, Nc / D
+    ah = ((3 * W - 6 * m) * (h * D) - Na * (D + h * Dh)) / (h * D)**2
+    bh = ((-4 * W + 6 * m) * D - Nb * Dh) / D**2
+    ch = (((2 * h + 4 * hi) * W + 6 * lo * m) * D - Nc * Dh) / D**2
+    am, bm, cm = -6 * (h + lo + hi) / (h * D), 6 * (h + 2 * hi) / D, 6 * lo * (h + 2 * hi) / D
+    # without slip at the lower wall u(0) = W exactly: keep c's derivatives exactly zero instead of a rounding residue
+    noslip = np.asarray(lo) == 0
+    c, ch = np.where(noslip, W, c), np.where(noslip, 0., ch)
+    return (a, b, c), (ah, bh, ch), (am, bm, cm)
+
+
+def viscous_general(where, q, h, U, V, eta, zeta, Ls, dqx=None, dqy=None, slip="top"):
+    """Newtonian stress of the parabolic profile at the lower wall (where=0), the upper wall (1) or averaged over the
+    gap (2), all six Voigt components, with gradient terms (viscous.py:37-786 in full generality).  slip="top": only
+    the upper wall slips; any other keyword: both walls (viscous.py:105, 427, 716 -- its second branch)."""
+    rho, jx, jy = q[0], q[1], q[2]
+    h0, hx, hy = h[0], h[1], h[2]
+    zero = np.zeros(np.broadcast(rho, h0).shape)
+    dqx = [zero, zero, zero] if dqx is None else dqx
+    dqy = [zero, zero, zero] if dqy is None else dqy
+    lo = 0. * Ls if slip == "top" else Ls
+    hi = Ls
+    mu, mv = jx / rho, jy / rho
+    (ua, ub, uc), uh, um = _slip_parabola(h0, U, mu, lo, hi)
+    (va, vb, vc), vh, vm = _slip_parabola(h0, V, mv, lo, hi)
+    w2 = {0: 0., 1: h0 * h0, 2: h0 * h0 / 3}[where]
+    w1 = {0: 0., 1: h0, 2: h0 / 2}[where]
+    at = lambda k: k[0] * w2 + k[1] * w1 + k[2]
+    mux, muy = (dqx[1] - mu * dqx[0]) / rho, (dqy[1] - mu * dqy[0]) / rho
+    mvx, mvy = (dqx[2] - mv * dqx[0]) / rho, (dqy[2] - mv * dqy[0]) / rho
+    ux, uy = at(uh) * hx + at(um) * mux, at(uh) * hy + at(um) * muy
+    vx, vy = at(vh) * hx + at(vm) * mvx, at(vh) * hy + at(vm) * mvy
+    zf = {0: 0., 1: 2 * h0, 2: h0}[where]
+    uz, vz = ua * zf + ub, va * zf + vb
+    v1 = zeta + 4 / 3 * eta
+    v2 = zeta - 2 / 3 * eta
+    return np.array([v1 * ux + v2 * vy, v2 * ux + v1 * vy, v2 * (ux + vy), eta * vz, eta * uz, eta * (uy + vx)])
+
+
+def stress_bottom(q, h, U, V, eta, zeta, Ls, dqx=None, dqy=None, slip="top"):
     """Lower-wall viscous stress, Voigt order xx,yy,zz,yz,xz,xy (viscous.py:37-278)."""
+    if slip != "top" or dqx is not None or dqy is not None:
+        return viscous_general(0, q, h, U, V, eta, zeta, Ls, dqx, dqy, slip)
     rho, jx, jy = q[0], q[1], q[2]
     h0, hx, hy = h[0], h[1], h[2]
     v1 = zeta + 4 / 3 * eta
@@ -226,11 +276,13 @@ def stress_bottom(q, h, U, V, eta, zeta, Ls, slip="top"):
         tau[3] = 2 * eta * (-6 * Ls * V * rho + 6 * Ls * jy - 2 * V * h0 * rho + 3 * h0 * jy) / (h0 * rho * (4 * Ls + h0))
         tau[4] = 2 * eta * (-6 * Ls * U * rho + 6 * Ls * jx - 2 * U * h0 * rho + 3 * h0 * jx) / (h0 * rho * (4 * Ls + h0))
         return tau
-    raise NotImplementedError(slip)    # other branches are off the solver path
+    raise AssertionError('unreachable')
 
 
-def stress_top(q, h, U, V, eta, zeta, Ls, slip="top"):
+def stress_top(q, h, U, V, eta, zeta, Ls, dqx=None, dqy=None, slip="top"):
     """Upper-wall viscous stress, Voigt order (viscous.py:281-609)."""
+    if slip != "top" or dqx is not None or dqy is not None:
+        return viscous_general(1, q, h, U, V, eta, zeta, Ls, dqx, dqy, slip)
     rho, jx, jy = q[0], q[1], q[2]
     h0, hx, hy = h[0], h[1], h[2]
     v1 = zeta + 4 / 3 * eta
@@ -254,18 +306,20 @@ def stress_top(q, h, U, V, eta, zeta, Ls, slip="top"):
                             - U * h0 * hy * rho**2 - V * h0 * hx * rho**2
                             + 3 * h0 * hx * rho * jy + 3 * h0 * hy * rho * jx) / den
         return tau
-    raise NotImplementedError(slip)
+    raise AssertionError('unreachable')
 
 
-def stress_avg(q, h, U, V, eta, zeta, Ls, slip="top"):
+def stress_avg(q, h, U, V, eta, zeta, Ls, dqx=None, dqy=None, slip="top"):
     """Gap-averaged viscous stress xx, yy, xy (viscous.py:612-786)."""
+    if slip not in ("top", "both"):         # viscous.py:663, 717: no third branch -- the array of zeros is returned
+        return np.zeros((3,) + np.broadcast(q[0], h[0], Ls).shape)
+    if slip != "top" or dqx is not None or dqy is not None:
+        return viscous_general(2, q, h, U, V, eta, zeta, Ls, dqx, dqy, slip)[[0, 1, 5]]
     rho, jx, jy = q[0], q[1], q[2]
     h0, hx, hy = h[0], h[1], h[2]
     v1 = zeta + 4 / 3 * eta
     v2 = zeta - 2 / 3 * eta
     tau = np.zeros((3,) + np.broadcast(rho, h0, Ls).shape)
-    if slip != "top":
-        raise NotImplementedError(slip)
     den = h0 * rho**2 * (4 * Ls + h0)       # viscous.py:663-715
 
     def norm(va, vb):

@@ -142,6 +142,32 @@ def leaf_fixtures():
     print('leaf_closures.npz:', len(out), 'arrays')
 
 
+def slip_fixtures():
+    """viscous.py in full generality: every slip keyword, with and without gradient terms, per-cell slip length."""
+    rng = np.random.default_rng(20261004)
+    shape = (5, 7)
+    out = {}
+    q = np.stack([rng.uniform(800., 950., shape), rng.uniform(-60., 60., shape), rng.uniform(-40., 40., shape)])
+    h = np.stack([rng.uniform(1e-6, 7e-5, shape), rng.uniform(-2e-3, 2e-3, shape), rng.uniform(-2e-3, 2e-3, shape)])
+    dqx = np.stack([rng.normal(size=shape) * 1e3, rng.normal(size=shape) * 1e4, rng.normal(size=shape) * 1e4])
+    dqy = np.stack([rng.normal(size=shape) * 1e3, rng.normal(size=shape) * 1e4, rng.normal(size=shape) * 1e4])
+    Ls = rng.uniform(0., 5e-6, shape)
+    Ls[0, :3] = 0.                          # no-slip cells inside a slipping field
+    U, V, eta, zeta = 0.1, -0.07, 0.0794, 0.013
+    out.update(q=q, h=h, dqx=dqx, dqy=dqy, Ls=Ls, params=np.array([U, V, eta, zeta]))
+    for slip in ('top', 'both', 'bottom', 'none'):
+        for tag, gx, gy in (('g0', None, None), ('g1', dqx, dqy)):
+            for name in ('stress_bottom', 'stress_top', 'stress_avg'):
+                r = getattr(ref_visc, name)(q, h, U, V, eta, zeta, Ls, dqx=gx, dqy=gy, slip=slip)
+                o = getattr(ocl, name)(q, h, U, V, eta, zeta, Ls, dqx=gx, dqy=gy, slip=slip)
+                scale = np.maximum(np.abs(r), np.abs(r).max(axis=(1, 2), keepdims=True) * 1e-3) + 1e-30
+                err = float(np.max(np.abs(o - r) / scale))
+                assert err <= 1e-11, f'{name} slip={slip} {tag}: oracle vs reference {err:.2e}'
+                out[f'{name}_{slip}_{tag}'] = r
+    np.savez_compressed(os.path.join(HERE, 'leaf_viscous_slip.npz'), **out)
+    print('leaf_viscous_slip.npz:', len(out), 'arrays')
+
+
 # ---------------------------------------------------------------------------
 # Step-level fixtures: reference leaf arithmetic + restated orchestration
 # ---------------------------------------------------------------------------
@@ -365,5 +391,9 @@ def step_fixtures():
 
 
 if __name__ == '__main__':
-    leaf_fixtures()
-    step_fixtures()
+    if sys.argv[1:] == ['slip']:            # only the newer fixture file; the others stay byte-identical
+        slip_fixtures()
+    else:
+        leaf_fixtures()
+        slip_fixtures()
+        step_fixtures()

@@ -82,3 +82,59 @@ def test_step_fixtures(name):
             np.testing.assert_allclose(prob.q, fx[f'q_{s}'], rtol=1e-12, atol=0)
             row = fx['history'][s - 1]
             np.testing.assert_allclose([prob.simtime, prob.dt, prob.kinetic_energy, prob.v_sound], row[[1, 2, 3, 5]], rtol=1e-12)
+
+
+SLIP = np.load(GOLDEN + '/leaf_viscous_slip.npz')
+
+
+def _slip_err(got, ref):
+    scale = np.maximum(np.abs(ref), np.abs(ref).max(axis=(1, 2), keepdims=True) * 1e-3) + 1e-30
+    return float(np.max(np.abs(got - ref) / scale))
+
+
+@pytest.mark.parametrize('slip', ['top', 'both', 'bottom', 'none'])
+@pytest.mark.parametrize('grad', ['g0', 'g1'])
+def test_viscous_stresses_every_slip_keyword(slip, grad):
+    """models/viscous.py in full generality (second branch = slip at both walls, gradient terms) against true reference
+    outputs.  The oracle derives these from the velocity model; the fixtures pin that derivation."""
+    q, h, Ls = SLIP['q'], SLIP['h'], SLIP['Ls']
+    U, V, eta, zeta = SLIP['params']
+    gx, gy = (SLIP['dqx'], SLIP['dqy']) if grad == 'g1' else (None, None)
+    for name in ('stress_bottom', 'stress_top', 'stress_avg'):
+        got = getattr(ocl, name)(q, h, U, V, eta, zeta, Ls, dqx=gx, dqy=gy, slip=slip)
+        assert _slip_err(got, SLIP[f'{name}_{slip}_{grad}']) <= 1e-11, name
+
+
+def test_general_slip_model_reduces_to_the_solver_branch():
+    """slip="top" through the general derivation == the closed forms the solver path uses (viscous.py:88-104, 333-426)."""
+    q, h, Ls = SLIP['q'], SLIP['h'], SLIP['Ls']
+    U, V, eta, zeta = SLIP['params']
+    for where, fn in ((0, ocl.stress_bottom), (1, ocl.stress_top)):
+        assert _slip_err(ocl.viscous_general(where, q, h, U, V, eta, zeta, Ls), fn(q, h, U, V, eta, zeta, Ls)) <= 1e-12
+    assert _slip_err(ocl.viscous_general(2, q, h, U, V, eta, zeta, Ls)[[0, 1, 5]], ocl.stress_avg(q, h, U, V, eta, zeta, Ls)) <= 1e-12
+
+
+@pytest.mark.parametrize('slip,Ls', [('both', 0.), ('both', 0.5), ('top', 0.), ('top', 0.5)])
+def test_wall_and_average_stress_are_consistent_with_the_profile(slip, Ls):
+    """tests/test_analytic.py:52-125 of the reference in spirit: the wall values are the ends of the stress profile across
+    the gap and the average is its integral.  The profile here is the oracle's parabola evaluated at many z."""
+    q = np.array([1.0, 0.75, 0.25])[:, None]
+    h = np.array([1.0, 0.01, 0.01])[:, None]
+    z = np.linspace(0., 1., 2001)
+    lo = 0. if slip == 'top' else Ls
+    prof = []
+    for W, m in ((1., q[1, 0] / q[0, 0]), (1., q[2, 0] / q[0, 0])):
+        (a, b, c), (ah, bh, ch), _ = ocl._slip_parabola(h[0, 0], W, m, lo, Ls)
+        prof.append((a * z**2 + b * z + c, 2 * a * z + b, ah * z**2 + bh * z + ch))
+    (u, uz, uh), (v, vz, vh) = prof
+    assert np.isclose(np.trapezoid(u, z), q[1, 0] / q[0, 0]) and np.isclose(np.trapezoid(v, z), q[2, 0] / q[0, 0])    # flow rate
+    eta = zeta = 1.
+    v1, v2 = zeta + 4 / 3 * eta, zeta - 2 / 3 * eta
+    ux, vy = uh * h[1, 0], vh * h[2, 0]
+    txx, tyy, txy = v1 * ux + v2 * vy, v2 * ux + v1 * vy, eta * (uh * h[2, 0] + vh * h[1, 0])
+    avg = ocl.stress_avg(q, h, 1., 1., eta, zeta, Ls, slip=slip)[:, 0]
+    np.testing.assert_allclose([np.trapezoid(txx, z), np.trapezoid(tyy, z), np.trapezoid(txy, z)], avg, rtol=1e-5)
+    bot = ocl.stress_bottom(q, h, 1., 1., eta, zeta, Ls, slip=slip)[:, 0]
+    top = ocl.stress_top(q, h, 1., 1., eta, zeta, Ls, slip=slip)[:, 0]
+    np.testing.assert_allclose([bot[0], bot[1], bot[3], bot[4], bot[5]], [txx[0], tyy[0], eta * vz[0], eta * uz[0], txy[0]], atol=1e-12)
+    np.testing.assert_allclose([top[0], top[1], top[3], top[4], top[5]], [txx[-1], tyy[-1], eta * vz[-1], eta * uz[-1], txy[-1]], atol=1e-12)
