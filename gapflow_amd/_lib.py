@@ -23,6 +23,10 @@ EOS_DEFAULTS = {'DH': {'rho0': 877.7007, 'P0': 101325., 'C1': 3.5e8, 'C2': 1.23}
 PIEZO_IDS = {'Barus': 1, 'Roelands': 2, 'Dukler': 3, 'McAdams': 4}
 PIEZO_KEYS = {'Barus': ['aB'], 'Roelands': ['mu_inf', 'p_ref', 'z'], 'Dukler': ['eta_v', 'rho_l', 'rho_v'],
               'McAdams': ['eta_v', 'rho_l', 'rho_v']}
+# defaults of the reference's viscosity laws (viscosity.py:144, 168, 200, 231, 262, 288)
+PIEZO_DEFAULTS = {'Barus': {'aB': 2.e-8}, 'Roelands': {'mu_inf': 1.e-3, 'p_ref': 1.96e8, 'z': 0.68},
+                  'Dukler': {'eta_v': 3.9e-5, 'rho_l': 850., 'rho_v': 0.019}, 'McAdams': {'eta_v': 3.9e-5, 'rho_l': 850., 'rho_v': 0.019}}
+THINNING_DEFAULTS = {'Eyring': {'tauE': 5.e5}, 'Carreau': {'mu_inf': 1.e-3, 'lam': 0.02, 'a': 2., 'N': 0.8}}
 THINNING_IDS = {'Eyring': 1, 'Carreau': 2}
 THINNING_KEYS = {'Eyring': ['tauE'], 'Carreau': ['mu_inf', 'lam', 'a', 'N']}
 BC_P, BC_D, BC_N = 0, 1, 2
@@ -75,6 +79,8 @@ SIGNATURES = {
     'gpf_state': (C.c_int, [C.c_void_p, C.POINTER(GpfScalars)]),
     'gpf_viscous_stress': (C.c_int, [C.c_int64] + [C.c_void_p] * 6 + [C.c_double] * 3 + [C.c_int] + [C.c_void_p] * 3),
     'gpf_eos': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'gpf_viscosity': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_double, C.c_double, C.c_void_p]),
     'gpf_p2p_export': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     'gpf_p2p_connect': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     'gpf_step_p2p': (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),

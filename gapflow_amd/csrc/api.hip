@@ -923,6 +923,41 @@ extern "C" int gpf_eos(int eos, const double* eos_par, int64_t n, const double* 
     return rc;
 }
 
+// models/viscosity.py as functions of arrays
+extern "C" int gpf_viscosity(int kind, int law, const double* par, double mu0, int64_t n, const double* a0, const double* a1,
+                             const double* a2, double u1, double u2, double* out) {
+    if (!a0 || !out || (kind == 2 && (!a1 || !a2)) || (kind != 2 && !par)) return fail(GPF_ERR_INVALID, "gpf_viscosity: null argument");
+    if (kind < 0 || kind > 2 || n < 1) return fail(GPF_ERR_INVALID, "gpf_viscosity: kind in 0..2 and n >= 1 required");
+    if ((kind == 0 && (law < 0 || law > GPF_PIEZO_MCADAMS)) || (kind == 1 && (law < 0 || law > GPF_THINNING_CARREAU)))
+        return fail(GPF_ERR_INVALID, "gpf_viscosity: unknown law");
+    if (gpf_device_count() == 0) return fail(GPF_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    gpf_config c;
+    std::memset(&c, 0, sizeof(c));
+    c.eos = GPF_EOS_DH; c.dx = c.dy = 1.0; c.eta = mu0;
+    c.eos_par[0] = 1.0; c.eos_par[2] = 1.0; c.eos_par[3] = 2.0;
+    if (kind == 0) { c.piezo = law; for (int i = 0; i < 4; ++i) c.piezo_par[i] = par[i]; }
+    if (kind == 1) { c.thinning = law; for (int i = 0; i < 4; ++i) c.thinning_par[i] = par[i]; }
+    Phys P;
+    make_phys(c, P);
+    const size_t N = (size_t)n;
+    double* d = nullptr;
+    HIP_TRY(hipMalloc(&d, 4 * N * sizeof(double)));
+    hipError_t e = hipMemcpy(d, a0, N * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && kind == 2) e = hipMemcpy(d + N, a1, N * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && kind == 2) e = hipMemcpy(d + 2 * N, a2, N * sizeof(double), hipMemcpyHostToDevice);
+    int rc = GPF_OK;
+    if (e != hipSuccess) {
+        rc = fail(GPF_ERR_HIP, hipGetErrorString(e));
+    } else {
+        hipLaunchKernelGGL(k_viscosity, dim3(blocks_for((long long)n)), dim3(256), 0, 0, kind, d, d + N, d + 2 * N, (long long)n,
+                           mu0, u1, u2, P, d + 3 * N);
+        if ((e = hipGetLastError()) != hipSuccess || (e = hipMemcpy(out, d + 3 * N, N * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess)
+            rc = fail(GPF_ERR_HIP, hipGetErrorString(e));
+    }
+    hipFree(d);
+    return rc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // slab decomposition
 // ---------------------------------------------------------------------------------------------

@@ -760,4 +760,14 @@ __global__ __launch_bounds__(256) void k_eos(const double* rho, long long n, Phy
     }
 }
 
+// models/viscosity.py: kind 0 piezoviscosity(arg, mu0), 1 shear_thinning_factor(rate, mu0), 2 shear_rate_avg(a0, a1, a2; u1, u2, mu0)
+__global__ __launch_bounds__(256) void k_viscosity(int kind, const double* a0, const double* a1, const double* a2, long long n,
+                                                   double mu0, double u1, double u2, Phys P, double* out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        if (kind == 0) out[i] = piezo_eta(mu0, a0[i], P);
+        else if (kind == 1) out[i] = thinning_factor(a0[i], mu0, P);
+        else out[i] = shear_rate_avg(a0[i], a1[i], a2[i], u1, u2, mu0);
+    }
+}
+
 }  // namespace gpf

@@ -231,20 +231,30 @@ GPF_HD double piezo_eta(double eta0, double arg, const Phys& P) {
 
 // Shear-thinning factor eta/mu0 at the mean wall shear rate of the Newtonian profile
 // (viscosity.py:69-141, 265-318; stress.py:314-324 passes U and V as the two wall velocities).
-GPF_HD double thinning_eta(double mu0, double dp_dx, double dp_dy, double h, const Phys& P) {
+// mean of the |wall shear rates| of the Newtonian profile between walls moving with u1, u2 (viscosity.py:110-141)
+GPF_HD double shear_rate_avg(double dp_dx, double dp_dy, double h, double u1, double u2, double mu) {
     const double gp = hypot(dp_dx, dp_dy);
-    const double du_p = h * gp / (2.0 * mu0);
-    const double du_c = (P.V - P.U) / h;
-    const double rate = (fabs(du_p + du_c) + fabs(-du_p + du_c)) / 2.0;
+    const double du_p = h * gp / (2.0 * mu);
+    const double du_c = (u2 - u1) / h;
+    return (fabs(du_p + du_c) + fabs(-du_p + du_c)) / 2.0;
+}
+
+// mu(shear rate) / mu0 (viscosity.py:69-96, 262-318)
+GPF_HD double thinning_factor(double rate, double mu0, const Phys& P) {
     if (P.thinning == THIN_EYRING) {
         const double tau0 = mu0 * rate;
-        return mu0 * (P.th[0] / tau0 * asinh(tau0 / P.th[0]));
+        return P.th[0] / tau0 * asinh(tau0 / P.th[0]);
     }
     if (P.thinning == THIN_CARREAU) {
         const double mu = P.th[0] + (mu0 - P.th[0]) * pow(1.0 + pow(P.th[1] * rate, P.th[2]), (P.th[3] - 1.0) / P.th[2]);
-        return mu0 * (mu / mu0);
+        return mu / mu0;
     }
-    return mu0;
+    return 1.0;
+}
+
+GPF_HD double thinning_eta(double mu0, double dp_dx, double dp_dy, double h, const Phys& P) {
+    if (P.thinning != THIN_EYRING && P.thinning != THIN_CARREAU) return mu0;
+    return mu0 * thinning_factor(shear_rate_avg(dp_dx, dp_dy, h, P.U, P.V, mu0), mu0, P);
 }
 
 // ---- one cell: fluxes and source ------------------------------------------------------------

@@ -213,6 +213,12 @@ int gpf_viscous_stress(int64_t n, const double* q, const double* hh, const doubl
 /* eos_pressure (models/pressure.py:35-76) and eos_sound_velocity (models/sound.py) of n densities; eos / eos_par as
  * in gpf_config; either output may be NULL. */
 int gpf_eos(int eos, const double* eos_par, int64_t n, const double* rho, double* pressure, double* sound);
+/* models/viscosity.py for n points.  kind 0: piezoviscosity(a0 = pressure, or density for the mixture laws; mu0;
+ * law = gpf_config.piezo, par = piezo_par) (viscosity.py:34-66); kind 1: shear_thinning_factor(a0 = shear rate; mu0;
+ * law = gpf_config.thinning, par = thinning_par) = mu/mu0 (viscosity.py:69-96); kind 2: shear_rate_avg(a0 = dp/dx,
+ * a1 = dp/dy, a2 = h; wall speeds u1, u2; viscosity mu0) (viscosity.py:110-141; law, par unused). */
+int gpf_viscosity(int kind, int law, const double* par, double mu0, int64_t n, const double* a0, const double* a1,
+                  const double* a2, double u1, double u2, double* out);
 
 /* ---- the unfused step in pieces ------------------------------------------------------------- */
 /* For closures that need the host between stages (GP surrogates with active learning, gp.py:435-506):

@@ -83,3 +83,21 @@ def test_eos_function_defaults(hiplib):
     np.testing.assert_allclose(eos_pressure(rho, {'EOS': 'PL'}), 101325. * (rho / 1.1853), rtol=1e-12)
     with pytest.raises(TypeError):
         eos_pressure(rho, {'EOS': 'BWR'})            # bwr(dens, T, ...) has no default temperature
+
+
+def test_viscosity_operators(hiplib):
+    """models/viscosity.py against the golden vectors of the reference's leaf module."""
+    from gapflow_amd.models import viscosity
+    pz = {'Barus': dict(name='Barus', aB=20e-9), 'Roelands': dict(name='Roelands', mu_inf=1e-3, p_ref=1.96e8, z=0.68),
+          'Dukler': dict(name='Dukler', eta_v=3.9e-5, rho_l=850., rho_v=0.019),
+          'McAdams': dict(name='McAdams', eta_v=3.9e-5, rho_l=850., rho_v=0.019)}
+    for k, d in pz.items():
+        arg = LEAF['piezo_rho'] if k in ('Dukler', 'McAdams') else LEAF['piezo_p']
+        np.testing.assert_allclose(viscosity.piezoviscosity(arg, 0.0794, d), LEAF[f'piezo_{k}'], rtol=1e-9)
+    th = {'Eyring': dict(name='Eyring', tauE=5e5), 'Carreau': dict(name='Carreau', mu_inf=1e-9, lam=1e-6, a=2., N=0.6)}
+    for k, d in th.items():
+        np.testing.assert_allclose(viscosity.shear_thinning_factor(LEAF['thin_sr'], 0.0794, d), LEAF[f'thin_{k}'], rtol=1e-9)
+    got = viscosity.shear_rate_avg(LEAF['sr_gx'], LEAF['sr_gy'], LEAF['sr_h'], 0.1, 0., 0.0794)
+    np.testing.assert_allclose(got, LEAF['sr_out'], rtol=1e-9)
+    # unknown law: viscosity unchanged (viscosity.py:63-64)
+    np.testing.assert_array_equal(viscosity.piezoviscosity(LEAF['piezo_p'], 0.0794, {'name': 'none'}), np.full(20, 0.0794))
