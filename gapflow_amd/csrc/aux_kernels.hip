@@ -234,34 +234,39 @@ struct FinishArgs {
     P2PArgs p2p;
 };
 
-// every block of the edge kernel: fold a slice of k_step's per-wave records into one record of its own
-__device__ inline void reduce_slice(const FinishArgs& a, Acc* sm) {
-    const int per = (a.nstep_partials + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int i0 = blockIdx.x * per, i1 = min(i0 + per, a.nstep_partials);
-    Acc acc; acc.zero();
-    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        const Partial p = a.partials[i];
-        acc.ekin += p.ekin; acc.v2 = nanmax(acc.v2, p.vmax2); acc.c2 = nanmax(acc.c2, p.c2max); acc.flags |= (int)p.flags;
-    }
-    acc = block_reduce(acc, sm);
-    if (threadIdx.x == 0) {
-        Partial p;
-        p.ekin = acc.ekin; p.vmax2 = acc.v2; p.c2max = acc.c2; p.flags = (double)acc.flags;
-        a.block_partials[blockIdx.x] = p;
-    }
+// The hand-over of the per-block records to the block that finishes the step uses no fences.  A device-scope release
+// writes back the XCD's whole L2 and costs 2-5 us PER BLOCK, serialised per XCD (measured: the same kernel with 160
+// blocks fencing took 32 us, with 34 blocks 16 us; tools/fence_probe.hip), so instead every hand-off word is
+//   - stored write-through by ONE lane (relaxed agent-scope atomic store = global_store ... sc1),
+//   - drained (s_waitcnt vmcnt(0)) by that lane before it -- the same lane -- adds to the arrival counter,
+//   - loaded by the last arriver with relaxed agent-scope atomic loads (sc1: served past the CU's L1), after the
+//     workgroup barrier that follows the add whose return value told it that it is last
+// (the 'write-through payload + counter + sc1 loads' form of the CDNA4 guide, Guideline 16 / MI355X_MICROARCH.md
+// "Valid forms").  Everything else these blocks store -- ghost cells, stage-1 pairs, the slab message -- is read by
+// LATER launches only.
+__device__ __forceinline__ void publish_partial(Partial* slot, const Acc& acc) {      // one lane
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(slot);
+    __hip_atomic_store(w + 0, (unsigned long long)__double_as_longlong(acc.ekin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w + 1, (unsigned long long)__double_as_longlong(acc.v2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w + 2, (unsigned long long)__double_as_longlong(acc.c2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w + 3, (unsigned long long)__double_as_longlong((double)acc.flags), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void merge_published(Acc& acc, const Partial* slot) {
+    const unsigned long long* w = reinterpret_cast<const unsigned long long*>(slot);
+    const double ekin = __longlong_as_double((long long)__hip_atomic_load(w + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const double v2 = __longlong_as_double((long long)__hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const double c2 = __longlong_as_double((long long)__hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const double fl = __longlong_as_double((long long)__hip_atomic_load(w + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    acc.ekin += ekin; acc.v2 = nanmax(acc.v2, v2); acc.c2 = nanmax(acc.c2, c2); acc.flags |= (int)fl;
 }
 
-// the last block: combine the blocks' records (slices of k_step's + the fill blocks' own) and commit, or -- slab --
-// publish this rank's record
+// the last block: combine the blocks' records and commit, or -- slab -- publish this rank's record
 __device__ inline void finish_tail(const FinishArgs& a, Acc* sm) {
     __shared__ double rec_sm[8];
     StepState* st = a.st;
     Acc acc; acc.zero();
-    const int nfill = a.npartials - a.nstep_partials, total = (int)gridDim.x + nfill;
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
-        const Partial p = i < (int)gridDim.x ? a.block_partials[i] : a.partials[a.nstep_partials + i - (int)gridDim.x];
-        acc.ekin += p.ekin; acc.v2 = nanmax(acc.v2, p.vmax2); acc.c2 = nanmax(acc.c2, p.c2max); acc.flags |= (int)p.flags;
-    }
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) merge_published(acc, a.block_partials + i);
     acc = block_reduce(acc, sm);
     if (threadIdx.x == 0) {
         if (a.out) {
@@ -278,8 +283,8 @@ __device__ inline void finish_tail(const FinishArgs& a, Acc* sm) {
         }
     }
     if (a.p2p.on) {
-        // message n = seq + 1: the rows are on their way (send_rows_block, fenced before the blocks arrived);
-        // now the record to everybody, then the flags
+        // message n = seq + 1: the rows are in the neighbours' mailboxes (send_rows_block: write-through stores,
+        // drained before the blocks arrived); now the record to everybody, then the flags
         __syncthreads();
         const P2PArgs& c = a.p2p;
         const unsigned long long n = *c.seq + 1;
@@ -287,27 +292,31 @@ __device__ inline void finish_tail(const FinishArgs& a, Acc* sm) {
         if (threadIdx.x < c.nranks) {
             MailHeader* hd = (MailHeader*)c.box[threadIdx.x];
             for (int k = 0; k < 8; ++k) hd->rec[slot][c.rank][k] = rec_sm[k];
-            // same thread, same peer: the release store orders the record (and, through the blocks' own release
-            // fences and the arrive counter, the rows) before the flag
+            // same lane, same peer: the system-scope release store orders the record before the flag
             __hip_atomic_store(&hd->flag[slot][c.rank], n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
 
-// Called by every block of the edge kernel when its own work is done: the last block to arrive finishes the step.
-// Fences are the expensive part here (a device-scope release or acquire costs 1-3 us on this chip: the XCDs' L2s are
-// not coherent with each other), so the hand-over uses exactly one release per block and one acquire.
-__device__ inline void finish_step(const FinishArgs& f, Acc* sm) {
+// Called by every block of the edge kernel when its own work is done, with the reductions over the cells it wrote
+// (`own`; zero for blocks that wrote none).  Folds in a slice of k_step's per-wave records, publishes one record per
+// block, and lets the last block to arrive finish the step.
+__device__ inline void finish_step(const FinishArgs& f, Acc own, Acc* sm) {
     __shared__ int last;
-    reduce_slice(f, sm);
-    if (f.p2p.on) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");         // rows stored into a peer's mailbox
-    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");             // this block's records and ghost cells
-    __syncthreads();
-    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(f.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+    const int per = (f.nstep_partials + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int i0 = blockIdx.x * per, i1 = min(i0 + per, f.nstep_partials);
+    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {       // written by k_step, an earlier launch: plain loads
+        const Partial p = f.partials[i];
+        own.ekin += p.ekin; own.v2 = nanmax(own.v2, p.vmax2); own.c2 = nanmax(own.c2, p.c2max); own.flags |= (int)p.flags;
+    }
+    own = block_reduce(own, sm);        // its barriers also put every wave's drained row stores before the arrival
+    if (threadIdx.x == 0) {
+        publish_partial(f.block_partials + blockIdx.x, own);
+        last = __hip_atomic_fetch_add(f.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+        if (last) __hip_atomic_store(f.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     if (!last) return;
-    if (threadIdx.x == 0) __hip_atomic_store(f.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                  // see what the other blocks wrote before they arrived
     finish_tail(f, sm);
 }
 
@@ -333,8 +342,12 @@ __device__ inline void send_rows_block(const double* q, const FinishArgs& f, int
         double v = 0.0;
         if (iy >= 1 && iy <= L.Ny) v = q[k * L.plane + (long long)ix * L.pitch + i];
         else if (iy == 0 || iy == L.Ny + 1) v = ghost_y(q, L, f.E, iy == 0 ? 2 : 3, k, ix);
-        dst[k * L.pitch + i] = v;
+        if (f.p2p.on)       // a peer's memory: write-through at system scope, drained below, before this block arrives
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst + k * L.pitch + i), (unsigned long long)__double_as_longlong(v),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else dst[k * L.pitch + i] = v;
     }
+    if (f.p2p.on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -353,7 +366,7 @@ struct GhostFillArgs {
 };
 
 template <int EOS>
-__device__ __forceinline__ void ghost_fill_block(const GhostFillArgs& a, const Phys& P, int block, int nblocks, Acc* sm) {
+__device__ __forceinline__ Acc ghost_fill_block(const GhostFillArgs& a, const Phys& P, int block, int nblocks) {
     const Layout& L = a.L;
     double* q = a.st->parity ? a.qa : a.qb;      // the buffer k_step has just written
     Acc acc; acc.zero();
@@ -392,23 +405,33 @@ __device__ __forceinline__ void ghost_fill_block(const GhostFillArgs& a, const P
             put(ix, e == 2 ? 0 : L.Ny + 1, v, w);
         }
     }
-    acc = block_reduce(acc, sm);
-    if (threadIdx.x == 0) {
-        Partial p;
-        p.ekin = acc.ekin; p.vmax2 = acc.v2; p.c2max = acc.c2; p.flags = (double)acc.flags;
-        a.partials[block] = p;
-    }
+    return acc;         // per thread; reduced in finish_step
 }
 
-// slab: blocks [0, nfill) fill ghost cells, the rest ship the two boundary rows; the last block done finishes the step
-template <int EOS>
-__global__ __launch_bounds__(256) void k_ghost_fill(const GhostFillArgs a, const FinishArgs f, int nfill, const Phys P) {
+// Edge work after k_step in ONE launch.  Blocks [0, nfill) write the ghost cells of the new field.  The others either
+// ship a slab's two boundary rows (SLAB), or -- undivided problem -- prepare the NEXT step's stage-1 ghost data as the
+// dt-independent pair (A', R'), reading the new field and deriving any ghost value they need from the interior by the
+// rules (the two jobs share no data).  The last block done finishes the step.
+template <int EOS, bool HAS_LS, bool SLAB>
+__global__ __launch_bounds__(256) void k_ghost_fill(const GhostFillArgs a, const FinishArgs f, int nfill, const GhostArgs g, const Phys P) {
     __shared__ Acc sm[4];
+    __shared__ double tiles[2][3][64];
     const StepState* st = a.st;
     if (st->invalid != 0 || (a.honor_stop && (st->converged || st->step >= st->max_it))) return;
-    if ((int)blockIdx.x < nfill) ghost_fill_block<EOS>(a, P, blockIdx.x, nfill, sm);
-    else send_rows_block(st->parity ? a.qa : a.qb, f, blockIdx.x - nfill, gridDim.x - nfill);
-    finish_step(f, sm);
+    Acc own; own.zero();
+    if ((int)blockIdx.x < nfill) {
+        own = ghost_fill_block<EOS>(a, P, blockIdx.x, nfill);
+    } else if (SLAB) {
+        send_rows_block(st->parity ? a.qa : a.qb, f, blockIdx.x - nfill, gridDim.x - nfill);
+    } else {
+        const Layout& L = a.L;
+        FilledField fld;
+        fld.q = st->parity ? a.qa : a.qb; fld.L = L; fld.E = a.E;
+        const int D = direction_of_step(st, st->step + 1);
+        const int ntiles = (L.Ny + L.Nx + 63) / 64, nprep = gridDim.x - nfill;
+        for (int tile = blockIdx.x - nfill; tile < ntiles; tile += nprep) ghost_stage1_tile<EOS, HAS_LS, false>(fld, g, P, D, tile * 64, 0.0, tiles);
+    }
+    finish_step(f, own, sm);
 }
 
 
@@ -468,6 +491,7 @@ struct WaitArgs {
 template <int EOS, bool HAS_LS>
 __global__ __launch_bounds__(256) void k_begin_p2p(const GhostArgs g, const WaitArgs a, const Phys P) {
     __shared__ int missing, last;
+    __shared__ double tiles[2][3][64];
     StepState* st = a.st;
     if (st->invalid != 0 || (a.honor_stop && (st->converged || st->step >= st->max_it))) return;
     const P2PArgs& c = a.p2p;
@@ -524,12 +548,8 @@ __global__ __launch_bounds__(256) void k_begin_p2p(const GhostArgs g, const Wait
         const int D = direction_of_step(st, st->step + 1);
         MailField fld;
         fld.q = q; fld.L = L; fld.row_lo = row_lo; fld.row_hi = row_hi;
-        const int t = blockIdx.x * blockDim.x + threadIdx.x;
-        if (blockIdx.y == 0) {
-            if (t + 1 <= L.Ny) ghost_stage1_row<EOS, HAS_LS>(fld, g, P, D, t + 1, dt);
-        } else {
-            if (t + 1 <= L.Nx) ghost_stage1_col<EOS, HAS_LS>(fld, g, P, D, t + 1, dt);
-        }
+        const int ntiles = (L.Ny + L.Nx + 63) / 64;
+        for (int tile = block; tile < ntiles; tile += nblocks) ghost_stage1_tile<EOS, HAS_LS, true>(fld, g, P, D, tile * 64, dt, tiles);
     }
     // the last block to get here writes the committed state (the others have read everything they need from it)
     __syncthreads();

@@ -50,8 +50,8 @@ struct StepArgs {
     const double* topo;         // h, hx, hy planes
     const double* topo_line;    // TOPO = 1: [3][Nx+2] profile over ix; TOPO = 2: [3][Ny+2] profile over iy
     const double* Ls;           // slip-length plane or nullptr
-    const double* g1x;          // [3][pitch]  stage-1 field on the downwind physical ghost row
-    const double* g1y;          // [3][Nx+2]   ... on the downwind physical ghost column
+    const double* g1x;          // [6][pitch]  stage-1 field on the downwind physical ghost row as (A', R'): q1 = A' - dt R'
+    const double* g1y;          // [6][Nx+2]   ... on the downwind physical ghost column
     const StepState* st;
     Partial* partials;          // one per (chunk, strip)
     Layout L;
@@ -157,9 +157,9 @@ __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, con
         // ---- stage 1 at (n, m) ----
         double q10, q11, q12;
         if (last && dw_row_is_ghost) {
-            q10 = a.g1x[0 * L.pitch + L.off + iy];
-            q11 = a.g1x[1 * L.pitch + L.off + iy];
-            q12 = a.g1x[2 * L.pitch + L.off + iy];
+            q10 = a.g1x[0 * L.pitch + L.off + iy] - dt * a.g1x[3 * L.pitch + L.off + iy];
+            q11 = a.g1x[1 * L.pitch + L.off + iy] - dt * a.g1x[4 * L.pitch + L.off + iy];
+            q12 = a.g1x[2 * L.pitch + L.off + iy] - dt * a.g1x[5 * L.pitch + L.off + iy];
         } else {
             CellFlux f;
             cell_closure<EOS, true, HAS_LS, PIEZO>(cur, tr, P, f);
@@ -170,9 +170,9 @@ __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, con
             q12 = cur.jy - dt * (cx * (f.fx2 - fx1p2) + cy * (fy2 - u2) - f.s2);
             fx1p0 = cur.jx; fx1p1 = f.fx1; fx1p2 = f.fx2;
             if (col_dw_ghost) {
-                q10 = a.g1y[0 * (L.Nx + 2) + ix];
-                q11 = a.g1y[1 * (L.Nx + 2) + ix];
-                q12 = a.g1y[2 * (L.Nx + 2) + ix];
+                q10 = a.g1y[0 * (L.Nx + 2) + ix] - dt * a.g1y[3 * (L.Nx + 2) + ix];
+                q11 = a.g1y[1 * (L.Nx + 2) + ix] - dt * a.g1y[4 * (L.Nx + 2) + ix];
+                q12 = a.g1y[2 * (L.Nx + 2) + ix] - dt * a.g1y[5 * (L.Nx + 2) + ix];
             }
         }
 
@@ -264,15 +264,20 @@ __global__ __launch_bounds__(256) void k_step(const StepArgs a, const Phys P) {
 //   periodic : q1(ghost) = q1(partner), partner = first interior cell on the other side
 //   Neumann  : q1(ghost) = q1(adjacent)                (problem.py:766)
 //   Dirichlet: q1(ghost) = 2*target - q1(adjacent)     (problem.py:758-764)
-// q1 at the source cell is the ordinary predictor result there: q1 = q - dt R.  k_step reads finished ghost values
-// g1 = rule(q - dt R), written by k_ghost_stage1 at the start of every step.
+// q1 at the source cell is the ordinary predictor result there: q1 = q - dt R, and every rule is affine,
+// rule(v) = s v + t (s = -1, t = 2 target for Dirichlet; s = 1, t = 0 otherwise).  k_step therefore reads the pair
+// (A', R') = (s q + t, s R) and forms A' - dt R' itself.  The pair does not depend on dt, so in the steady loop of an
+// undivided problem it is prepared right after the field of step n is complete -- in the same launch as the ghost fill
+// of step n (k_ghost_fill's prepass blocks), before step n's dt is even committed.  After an upload, and for slabs (whose
+// outer rows arrive later), k_ghost_stage1 / k_begin_p2p do the same job at the start of the step; they know dt and
+// store the finished value (A' = rule(q - dt R), R' = 0).
 // ---------------------------------------------------------------------------------------------
 struct GhostArgs {
     const double* qa; const double* qb;
     const double* topo; const double* Ls;
     const double* seam[2];      // per x edge: [2 rows][4: h,hx,hy,Ls][pitch] = topography of (source row, its
                                 // upwind row) on the far side of a periodic slab seam, or nullptr
-    double* g1x; double* g1y;   // finished ghost values [3][pitch], [3][Nx+2]
+    double* g1x; double* g1y;   // (A', R') pairs [6][pitch], [6][Nx+2]
     const StepState* st;
     Layout L; Edges E;
     int honor_stop;
@@ -284,6 +289,28 @@ struct StoredField {
     const double* q; Layout L;
     __device__ __forceinline__ double get(int ix, int iy, int c) const { return q[c * L.plane + L.at(ix, iy)]; }
 };
+// The interior of a freshly written field with its physical ghost cells derived on the fly by the ghost rules
+// (x rule, then y rule: the reference's order, so corners agree) -- what k_ghost_fill's fill blocks are writing
+// while its prepass blocks read.
+struct FilledField {
+    const double* q; Layout L; Edges E;
+    __device__ __forceinline__ double get(int ix, int iy, int c) const {
+        int sx = ix, sy = iy, ex = -1, ey = -1;
+        if (ix == 0 || ix == L.Nx + 1) {
+            ex = ix == 0 ? 0 : 1;
+            sx = E.rule[ex][0] == BC_P ? (ex == 0 ? L.Nx : 1) : (ex == 0 ? 1 : L.Nx);
+        }
+        if (iy == 0 || iy == L.Ny + 1) {
+            ey = iy == 0 ? 2 : 3;
+            sy = E.rule[ey][0] == BC_P ? (ey == 2 ? L.Ny : 1) : (ey == 2 ? 1 : L.Ny);
+        }
+        double v = q[c * L.plane + L.at(sx, sy)];
+        if (ex >= 0) v = ghost_rule(E, ex, c, v);
+        if (ey >= 0) v = ghost_rule(E, ey, c, v);
+        return v;
+    }
+};
+
 // A slab's field whose two outer rows are still in this rank's mailbox (peer-to-peer transport): what StoredField
 // will show once the rows have been scattered.
 struct MailField {
@@ -296,13 +323,66 @@ struct MailField {
     }
 };
 
-template <int EOS, bool HAS_LS, class Field>
-__device__ __forceinline__ void stage1_rate(const Field& fld, const GhostArgs& a, const Phys& P, int D, int ix, int iy,
-                                            const double* tsrc, const double* tup, const double* lsrc, const double* lup,
-                                            int ixq_up, double A[3], double R[3]) {
-    // (ix, iy): source cell; x-upwind neighbour is (ix - D, iy) -- or row ixq_up of q when the caller
-    // redirects it across a slab seam; y-upwind neighbour is (ix, iy - D).  tsrc/tup: optional topo rows.
+// Work item t of a step's stage-1 ghost data: t in [0, Ny) is column t+1 of the downwind ghost ROW, t in [Ny, Ny+Nx)
+// is row t-Ny+1 of the downwind ghost COLUMN.  Its value needs the predictor rate R at a source cell, i.e. closures at
+// three cells: the source (with the source term), its x-upwind and its y-upwind neighbour.
+struct Stage1Item {
+    bool active, row;
+    int edge;                       // whose rule applies: 0/1 for a row, 2/3 for a column
+    int ix_src, iy_src, ix_up;      // source cell; x-upwind row (redirected across a slab seam)
+    const double *ts, *tu, *ls, *lu;    // optional topography rows of (source, upwind) beyond a periodic slab seam
+    int out;                        // index into g1x / g1y
+};
+
+__device__ __forceinline__ Stage1Item stage1_item(const GhostArgs& a, int D, int t) {
     const Layout& L = a.L;
+    Stage1Item it;
+    it.active = t < L.Ny + L.Nx;
+    it.row = t < L.Ny;
+    it.ts = it.tu = it.ls = it.lu = nullptr;
+    if (it.row) {
+        const int iy = t + 1;
+        it.edge = D > 0 ? 1 : 0;
+        if (a.E.halo[it.edge] == 1) it.active = false;         // a neighbour's real cell: the stencil computes it
+        const bool periodic = a.E.rule[it.edge][0] == BC_P;
+        if (!periodic) {
+            it.ix_src = D > 0 ? L.Nx : 1;
+            it.ix_up = it.ix_src - D;
+        } else if (a.E.halo[it.edge] != 2) {
+            it.ix_src = D > 0 ? 1 : L.Nx;                       // partner cell on the other side of the domain
+            it.ix_up = it.ix_src - D;
+        } else {
+            // periodic seam between slabs: the partner row's q sits in this slab's halo/ghost row, its upwind
+            // neighbour is this slab's last interior row; their topography is static data
+            it.ix_src = D > 0 ? L.Nx + 1 : 0;
+            it.ix_up = D > 0 ? L.Nx : 1;
+            it.ts = a.seam[it.edge]; it.tu = a.seam[it.edge] + 4 * L.pitch;
+            it.ls = it.ts + 3 * L.pitch; it.lu = it.tu + 3 * L.pitch;
+        }
+        it.iy_src = iy;
+        it.out = L.off + iy;
+    } else {
+        const int ix = t - L.Ny + 1;
+        it.edge = D > 0 ? 3 : 2;
+        const bool periodic = a.E.rule[it.edge][0] == BC_P;
+        it.iy_src = periodic ? (D > 0 ? 1 : L.Ny) : (D > 0 ? L.Ny : 1);
+        it.ix_src = ix;
+        it.ix_up = ix - D;
+        it.out = ix;
+    }
+    return it;
+}
+
+// One tile of 64 work items by a 256-thread block.  The three closures of an item are evaluated by three different
+// WAVES (wave 0: source cell, wave 1: x-upwind, wave 2: y-upwind; wave 3 idles), which cuts the dependent arithmetic
+// chain of this latency-bound job to a third; the upwind fluxes travel through LDS.
+// FINAL: dt is known, store (rule(q - dt R), 0); otherwise store the dt-independent pair (s q + t, s R).
+template <int EOS, bool HAS_LS, bool FINAL, class Field>
+__device__ __forceinline__ void ghost_stage1_tile(const Field& fld, const GhostArgs& a, const Phys& P, int D, int t0, double dt,
+                                                  double (*sm)[3][64]) {
+    const Layout& L = a.L;
+    const int role = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const Stage1Item it = stage1_item(a, D, t0 + lane);
     auto cell = [&](int cx_, int cy_, const double* trow, const double* lrow, CellIn& c) {
         c.rho = fld.get(cx_, cy_, 0); c.jx = fld.get(cx_, cy_, 1); c.jy = fld.get(cx_, cy_, 2);
         if (trow) {
@@ -314,76 +394,59 @@ __device__ __forceinline__ void stage1_rate(const Field& fld, const GhostArgs& a
             c.Ls = HAS_LS ? a.Ls[o] : 0.0;
         }
     };
-    CellIn c, cxu, cyu;
-    cell(ix, iy, tsrc, lsrc, c);
-    cell(ixq_up, iy, tup, lup, cxu);
-    cell(ix, iy - D, tsrc, lsrc, cyu);
-    CellFlux f, fxu, fyu;
-    cell_closure<EOS, true, HAS_LS, true>(c, P, f);
-    cell_closure<EOS, false, HAS_LS, true>(cxu, P, fxu);
-    cell_closure<EOS, false, HAS_LS, true>(cyu, P, fyu);
-    const double cx = (double)D * P.inv_dx, cy = (double)D * P.inv_dy;
-    A[0] = c.rho; A[1] = c.jx; A[2] = c.jy;
-    R[0] = cx * (c.jx - cxu.jx) + cy * (c.jy - cyu.jy) - f.s0;
-    R[1] = cx * (f.fx1 - fxu.fx1) + cy * (f.fx2 - fyu.fx2) - f.s1;
-    R[2] = cx * (f.fx2 - fxu.fx2) + cy * (f.fy2 - fyu.fy2) - f.s2;
-}
-
-// one interior column iy of the downwind ghost ROW
-template <int EOS, bool HAS_LS, class Field>
-__device__ __forceinline__ void ghost_stage1_row(const Field& fld, const GhostArgs& a, const Phys& P, int D, int iy, double dt) {
-    const Layout& L = a.L;
-    const int edge = D > 0 ? 1 : 0;
-    if (a.E.halo[edge] == 1) return;           // a neighbour's real cell: the stencil computes it
-    const bool periodic = a.E.rule[edge][0] == BC_P;
-    int ix_src, ix_up;
-    const double *ts = nullptr, *tu = nullptr, *ls = nullptr, *lu = nullptr;
-    if (!periodic) {
-        ix_src = D > 0 ? L.Nx : 1;
-        ix_up = ix_src - D;
-    } else if (a.E.halo[edge] != 2) {
-        ix_src = D > 0 ? 1 : L.Nx;              // partner cell on the other side of the domain
-        ix_up = ix_src - D;
-    } else {
-        // periodic seam between slabs: the partner row's q sits in this slab's halo/ghost row,
-        // its upwind neighbour is this slab's last interior row; their topography is static data
-        ix_src = D > 0 ? L.Nx + 1 : 0;
-        ix_up = D > 0 ? L.Nx : 1;
-        ts = a.seam[edge]; tu = a.seam[edge] + 4 * L.pitch;
-        ls = ts + 3 * L.pitch; lu = tu + 3 * L.pitch;
+    CellIn c;
+    CellFlux f;
+    if (it.active) {
+        if (role == 0) {
+            cell(it.ix_src, it.iy_src, it.ts, it.ls, c);
+            cell_closure<EOS, true, HAS_LS, true>(c, P, f);
+        } else if (role == 1) {
+            cell(it.ix_up, it.iy_src, it.tu, it.lu, c);
+            cell_closure<EOS, false, HAS_LS, true>(c, P, f);
+            sm[0][0][lane] = c.jx; sm[0][1][lane] = f.fx1; sm[0][2][lane] = f.fx2;
+        } else if (role == 2) {
+            cell(it.ix_src, it.iy_src - D, it.ts, it.ls, c);
+            cell_closure<EOS, false, HAS_LS, true>(c, P, f);
+            sm[1][0][lane] = c.jy; sm[1][1][lane] = f.fx2; sm[1][2][lane] = f.fy2;
+        }
     }
-    double A[3], R[3];
-    stage1_rate<EOS, HAS_LS>(fld, a, P, D, ix_src, iy, ts, tu, ls, lu, ix_up, A, R);
-    for (int c = 0; c < 3; ++c) a.g1x[c * L.pitch + L.off + iy] = ghost_rule(a.E, edge, c, A[c] - dt * R[c]);
+    __syncthreads();
+    if (it.active && role == 0) {
+        const double cx = (double)D * P.inv_dx, cy = (double)D * P.inv_dy;
+        const double A[3] = {c.rho, c.jx, c.jy};
+        double R[3];
+        R[0] = cx * (c.jx - sm[0][0][lane]) + cy * (c.jy - sm[1][0][lane]) - f.s0;
+        R[1] = cx * (f.fx1 - sm[0][1][lane]) + cy * (f.fx2 - sm[1][1][lane]) - f.s1;
+        R[2] = cx * (f.fx2 - sm[0][2][lane]) + cy * (f.fy2 - sm[1][2][lane]) - f.s2;
+        double* g = it.row ? a.g1x : a.g1y;
+        const int stride = it.row ? L.pitch : L.Nx + 2;
+        for (int k = 0; k < 3; ++k) {
+            const int o = k * stride + it.out;
+            if (FINAL) {
+                g[o] = ghost_rule(a.E, it.edge, k, A[k] - dt * R[k]);
+                g[o + 3 * stride] = 0.0;
+            } else {
+                g[o] = ghost_rule(a.E, it.edge, k, A[k]);
+                g[o + 3 * stride] = a.E.rule[it.edge][k] == BC_D ? -R[k] : R[k];
+            }
+        }
+    }
+    __syncthreads();                // the LDS tile is free again
 }
 
-// one interior row ix of the downwind ghost COLUMN
-template <int EOS, bool HAS_LS, class Field>
-__device__ __forceinline__ void ghost_stage1_col(const Field& fld, const GhostArgs& a, const Phys& P, int D, int ix, double dt) {
-    const Layout& L = a.L;
-    const int edge = D > 0 ? 3 : 2;
-    const bool periodic = a.E.rule[edge][0] == BC_P;
-    const int iy_src = periodic ? (D > 0 ? 1 : L.Ny) : (D > 0 ? L.Ny : 1);
-    double A[3], R[3];
-    stage1_rate<EOS, HAS_LS>(fld, a, P, D, ix, iy_src, nullptr, nullptr, nullptr, nullptr, ix - D, A, R);
-    for (int c = 0; c < 3; ++c) a.g1y[c * (L.Nx + 2) + ix] = ghost_rule(a.E, edge, c, A[c] - dt * R[c]);
-}
-
-// stage-1 ghost data of the step about to run, from the stored field (ghost cells and halo rows included)
+// stage-1 ghost data of the step about to run, from the stored field (ghost cells and halo rows included): after an
+// upload, and at the start of every step of a slab on the all-gather transport
 template <int EOS, bool HAS_LS>
 __global__ __launch_bounds__(256) void k_ghost_stage1(const GhostArgs a, const Phys P) {
+    __shared__ double sm[2][3][64];
     if (halted(a.st, a.honor_stop)) return;
     const Layout& L = a.L;
     StoredField fld;
     fld.q = a.st->parity ? a.qb : a.qa; fld.L = L;
     const int D = predictor_direction(a.st);
     const double dt = a.st->dt;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.y == 0) {
-        if (t + 1 <= L.Ny) ghost_stage1_row<EOS, HAS_LS>(fld, a, P, D, t + 1, dt);
-    } else {
-        if (t + 1 <= L.Nx) ghost_stage1_col<EOS, HAS_LS>(fld, a, P, D, t + 1, dt);
-    }
+    const int ntiles = (L.Ny + L.Nx + 63) / 64;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) ghost_stage1_tile<EOS, HAS_LS, true>(fld, a, P, D, tile * 64, dt, sm);
 }
 
 }  // namespace gpf
