@@ -51,7 +51,7 @@ struct gpf_handle {
     double* topo_line = nullptr;            // [3][max(Nx,Ny)+2]: the profile when the topography varies along one axis only
     int topo_mode = 0;                      // 0: 2-D planes, 1: function of ix only, 2: function of iy only
     double* Ls = nullptr;                   // 1 plane (allocated on first non-zero upload)
-    double* g1 = nullptr;                   // g1x [6][pitch], g1y [6][Nx+2]: stage-1 ghost values of the step about to run as (A', R')
+    double* g1 = nullptr;                   // g1x [3][pitch], g1y [3][Nx+2]: stage-1 ghost values of the step about to run
     double* seam = nullptr;                 // [2 edges][2 rows][4: h,hx,hy,Ls][pitch]
     bool has_seam[2] = {false, false};
     // peer-to-peer slab transport (gpf_p2p_*): my mailbox, every rank's mailbox as mapped here, message counter
@@ -256,7 +256,7 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
     }
     HIP_TRY_C(hipMalloc(&h->topo, 3 * plane_b));
     HIP_TRY_C(hipMemset(h->topo, 0, 3 * plane_b));
-    const size_t g1n = (size_t)6 * L.pitch + (size_t)6 * (L.Nx + 2);
+    const size_t g1n = (size_t)3 * L.pitch + (size_t)3 * (L.Nx + 2);
     HIP_TRY_C(hipMalloc(&h->g1, g1n * sizeof(double)));
     HIP_TRY_C(hipMemset(h->g1, 0, g1n * sizeof(double)));
     HIP_TRY_C(hipMalloc(&h->st, sizeof(StepState)));
@@ -640,7 +640,7 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     const int np_step = h->nstrips * h->nchunks;
     StepArgs a;
     a.qa = h->q[0]; a.qb = h->q[1]; a.topo = h->topo; a.topo_line = h->topo_line; a.Ls = h->Ls;
-    a.g1x = h->g1; a.g1y = h->g1 + 6 * L.pitch;
+    a.g1x = h->g1; a.g1y = h->g1 + 3 * L.pitch;
     a.st = h->st; a.partials = h->partials; a.L = L; a.E = h->E;
     a.rows_per_chunk = h->rows_per_chunk; a.nstrips = h->nstrips; a.honor_stop = honor_stop;
     GhostArgs g;
@@ -652,7 +652,7 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
             g.seam[e] = h->seam + (size_t)e * 8 * L.pitch;
         }
     }
-    g.g1x = h->g1; g.g1y = h->g1 + 6 * L.pitch;
+    g.g1x = h->g1; g.g1y = h->g1 + 3 * L.pitch;
     g.st = h->st; g.L = L; g.E = h->E; g.honor_stop = honor_stop;
     const bool slab = slab_out != nullptr;
     FinishArgs f;
@@ -667,16 +667,16 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     gf.L = L; gf.E = h->E; gf.honor_stop = honor_stop;
 
     // Launches per step:
-    //   undivided problem: k_step, k_ghost_fill (ghost cells of the new field + the next step's stage-1 ghost data as
-    //       dt-independent pairs; its last block reduces all records and commits dt, residual, step) -- two launches;
-    //       after an upload k_ghost_stage1 prepares the first step's ghost data from the stored field
-    //   slab, all-gather transport: k_ghost_stage1, k_step, k_ghost_fill (ghost cells + boundary rows into the message)
-    //   slab, peer-to-peer: k_step, k_ghost_fill (rows into the neighbours' mailboxes), k_begin_p2p (wait for the
-    //       peers' rows and records, commit, stage-1 ghost data of the next step)
+    //   k_ghost_stage1  stage-1 values on the downwind ghost row / column (needs the dt the previous step committed)
+    //   k_step          the fused predictor + corrector + average over the interior
+    //   k_ghost_fill    ghost cells of the new field (+ a slab's boundary rows into its message / its peers'
+    //                   mailboxes); its last block to finish reduces all records and commits dt, residual, step
+    //   peer-to-peer slabs: k_begin_p2p (wait for the peers' rows and records, commit, k_ghost_stage1's job for the
+    //                   next step) takes the place of the next step's k_ghost_stage1
     const int ntiles = (L.Nx + L.Ny + 63) / 64;                 // stage-1 ghost work: 64 items per block
     const dim3 ggrid(std::min(ntiles, 512)), sgrid((h->nstrips + 3) / 4, h->nchunks);
     const step_kernel_t kstep = step_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, D, topo_mode_of(h));
-    const int nextra = slab ? std::min((6 * L.pitch + 1023) / 1024, 256) : std::min(ntiles, 512);   // block_partials holds 1024
+    const int nsend = slab ? std::min((6 * L.pitch + 1023) / 1024, 256) : 0;        // block_partials holds 1024
     WaitArgs w;
     w.qa = h->q[0]; w.qb = h->q[1]; w.st = h->st; w.log = h->log; w.log_base = log_base; w.log_cap = h->log_cap;
     w.L = L; w.E = h->E; w.honor_stop = honor_stop; w.arrive = h->arrive + 1; w.p2p = f.p2p;
@@ -689,20 +689,13 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
         if (ev0) hipEventRecord(ev0, h->stream);
         hipLaunchKernelGGL(kstep, sgrid, dim3(256), 0, h->stream, a, h->P);
         if (ev1) hipEventRecord(ev1, h->stream);
-        const dim3 egrid(h->nghost_blocks + nextra);
-        if (slab) {
-            if (has_ls) hipLaunchKernelGGL((k_ghost_fill<EOS_, true, true>), egrid, dim3(256), 0, h->stream, gf, f, h->nghost_blocks, g, h->P);
-            else hipLaunchKernelGGL((k_ghost_fill<EOS_, false, true>), egrid, dim3(256), 0, h->stream, gf, f, h->nghost_blocks, g, h->P);
-        } else {
-            if (has_ls) hipLaunchKernelGGL((k_ghost_fill<EOS_, true, false>), egrid, dim3(256), 0, h->stream, gf, f, h->nghost_blocks, g, h->P);
-            else hipLaunchKernelGGL((k_ghost_fill<EOS_, false, false>), egrid, dim3(256), 0, h->stream, gf, f, h->nghost_blocks, g, h->P);
-        }
+        hipLaunchKernelGGL((k_ghost_fill<EOS_>), dim3(h->nghost_blocks + nsend), dim3(256), 0, h->stream, gf, f, h->nghost_blocks, h->P);
         if (p2p) {                          // wait for the peers, commit, stage-1 ghost data of the next step
             if (has_ls) hipLaunchKernelGGL((k_begin_p2p<EOS_, true>), ggrid, dim3(256), 0, h->stream, g, w, h->P);
             else hipLaunchKernelGGL((k_begin_p2p<EOS_, false>), ggrid, dim3(256), 0, h->stream, g, w, h->P);
         }
     });
-    h->g1_ready = p2p || !slab;        // the next step's ghost data is in place unless the slab still waits for rows
+    h->g1_ready = p2p;                  // k_begin_p2p has prepared the next step's ghost data
     HIP_TRY(hipGetLastError());
     return GPF_OK;
 }

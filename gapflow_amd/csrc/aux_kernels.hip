@@ -408,29 +408,16 @@ __device__ __forceinline__ Acc ghost_fill_block(const GhostFillArgs& a, const Ph
     return acc;         // per thread; reduced in finish_step
 }
 
-// Edge work after k_step in ONE launch.  Blocks [0, nfill) write the ghost cells of the new field.  The others either
-// ship a slab's two boundary rows (SLAB), or -- undivided problem -- prepare the NEXT step's stage-1 ghost data as the
-// dt-independent pair (A', R'), reading the new field and deriving any ghost value they need from the interior by the
-// rules (the two jobs share no data).  The last block done finishes the step.
-template <int EOS, bool HAS_LS, bool SLAB>
-__global__ __launch_bounds__(256) void k_ghost_fill(const GhostFillArgs a, const FinishArgs f, int nfill, const GhostArgs g, const Phys P) {
+// Edge work after k_step in ONE launch: blocks [0, nfill) write the ghost cells of the new field, the others (slabs
+// only) ship the two boundary rows; the last block done finishes the step.
+template <int EOS>
+__global__ __launch_bounds__(256) void k_ghost_fill(const GhostFillArgs a, const FinishArgs f, int nfill, const Phys P) {
     __shared__ Acc sm[4];
-    __shared__ double tiles[2][3][64];
     const StepState* st = a.st;
     if (st->invalid != 0 || (a.honor_stop && (st->converged || st->step >= st->max_it))) return;
     Acc own; own.zero();
-    if ((int)blockIdx.x < nfill) {
-        own = ghost_fill_block<EOS>(a, P, blockIdx.x, nfill);
-    } else if (SLAB) {
-        send_rows_block(st->parity ? a.qa : a.qb, f, blockIdx.x - nfill, gridDim.x - nfill);
-    } else {
-        const Layout& L = a.L;
-        FilledField fld;
-        fld.q = st->parity ? a.qa : a.qb; fld.L = L; fld.E = a.E;
-        const int D = direction_of_step(st, st->step + 1);
-        const int ntiles = (L.Ny + L.Nx + 63) / 64, nprep = gridDim.x - nfill;
-        for (int tile = blockIdx.x - nfill; tile < ntiles; tile += nprep) ghost_stage1_tile<EOS, HAS_LS, false>(fld, g, P, D, tile * 64, 0.0, tiles);
-    }
+    if ((int)blockIdx.x < nfill) own = ghost_fill_block<EOS>(a, P, blockIdx.x, nfill);
+    else send_rows_block(st->parity ? a.qa : a.qb, f, blockIdx.x - nfill, gridDim.x - nfill);
     finish_step(f, own, sm);
 }
 
@@ -549,7 +536,7 @@ __global__ __launch_bounds__(256) void k_begin_p2p(const GhostArgs g, const Wait
         MailField fld;
         fld.q = q; fld.L = L; fld.row_lo = row_lo; fld.row_hi = row_hi;
         const int ntiles = (L.Ny + L.Nx + 63) / 64;
-        for (int tile = block; tile < ntiles; tile += nblocks) ghost_stage1_tile<EOS, HAS_LS, true>(fld, g, P, D, tile * 64, dt, tiles);
+        for (int tile = block; tile < ntiles; tile += nblocks) ghost_stage1_tile<EOS, HAS_LS>(fld, g, P, D, tile * 64, dt, tiles);
     }
     // the last block to get here writes the committed state (the others have read everything they need from it)
     __syncthreads();

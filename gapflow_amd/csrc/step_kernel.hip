@@ -50,8 +50,8 @@ struct StepArgs {
     const double* topo;         // h, hx, hy planes
     const double* topo_line;    // TOPO = 1: [3][Nx+2] profile over ix; TOPO = 2: [3][Ny+2] profile over iy
     const double* Ls;           // slip-length plane or nullptr
-    const double* g1x;          // [6][pitch]  stage-1 field on the downwind physical ghost row as (A', R'): q1 = A' - dt R'
-    const double* g1y;          // [6][Nx+2]   ... on the downwind physical ghost column
+    const double* g1x;          // [3][pitch]  stage-1 field on the downwind physical ghost row
+    const double* g1y;          // [3][Nx+2]   ... on the downwind physical ghost column
     const StepState* st;
     Partial* partials;          // one per (chunk, strip)
     Layout L;
@@ -157,9 +157,9 @@ __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, con
         // ---- stage 1 at (n, m) ----
         double q10, q11, q12;
         if (last && dw_row_is_ghost) {
-            q10 = a.g1x[0 * L.pitch + L.off + iy] - dt * a.g1x[3 * L.pitch + L.off + iy];
-            q11 = a.g1x[1 * L.pitch + L.off + iy] - dt * a.g1x[4 * L.pitch + L.off + iy];
-            q12 = a.g1x[2 * L.pitch + L.off + iy] - dt * a.g1x[5 * L.pitch + L.off + iy];
+            q10 = a.g1x[0 * L.pitch + L.off + iy];
+            q11 = a.g1x[1 * L.pitch + L.off + iy];
+            q12 = a.g1x[2 * L.pitch + L.off + iy];
         } else {
             CellFlux f;
             cell_closure<EOS, true, HAS_LS, PIEZO>(cur, tr, P, f);
@@ -170,9 +170,9 @@ __device__ __forceinline__ void step_strip(const StepArgs& a, const Phys& P, con
             q12 = cur.jy - dt * (cx * (f.fx2 - fx1p2) + cy * (fy2 - u2) - f.s2);
             fx1p0 = cur.jx; fx1p1 = f.fx1; fx1p2 = f.fx2;
             if (col_dw_ghost) {
-                q10 = a.g1y[0 * (L.Nx + 2) + ix] - dt * a.g1y[3 * (L.Nx + 2) + ix];
-                q11 = a.g1y[1 * (L.Nx + 2) + ix] - dt * a.g1y[4 * (L.Nx + 2) + ix];
-                q12 = a.g1y[2 * (L.Nx + 2) + ix] - dt * a.g1y[5 * (L.Nx + 2) + ix];
+                q10 = a.g1y[0 * (L.Nx + 2) + ix];
+                q11 = a.g1y[1 * (L.Nx + 2) + ix];
+                q12 = a.g1y[2 * (L.Nx + 2) + ix];
             }
         }
 
@@ -264,20 +264,18 @@ __global__ __launch_bounds__(256) void k_step(const StepArgs a, const Phys P) {
 //   periodic : q1(ghost) = q1(partner), partner = first interior cell on the other side
 //   Neumann  : q1(ghost) = q1(adjacent)                (problem.py:766)
 //   Dirichlet: q1(ghost) = 2*target - q1(adjacent)     (problem.py:758-764)
-// q1 at the source cell is the ordinary predictor result there: q1 = q - dt R, and every rule is affine,
-// rule(v) = s v + t (s = -1, t = 2 target for Dirichlet; s = 1, t = 0 otherwise).  k_step therefore reads the pair
-// (A', R') = (s q + t, s R) and forms A' - dt R' itself.  The pair does not depend on dt, so in the steady loop of an
-// undivided problem it is prepared right after the field of step n is complete -- in the same launch as the ghost fill
-// of step n (k_ghost_fill's prepass blocks), before step n's dt is even committed.  After an upload, and for slabs (whose
-// outer rows arrive later), k_ghost_stage1 / k_begin_p2p do the same job at the start of the step; they know dt and
-// store the finished value (A' = rule(q - dt R), R' = 0).
+// q1 at the source cell is the ordinary predictor result there: q1 = q - dt R.  k_step reads finished ghost values
+// g1 = rule(q - dt R), written at the start of every step by k_ghost_stage1 (or, for slabs on the peer-to-peer
+// transport, by the previous step's k_begin_p2p).  Handing k_step the dt-independent pair (rule-folded q, R) instead --
+// prepared one launch earlier, inside the ghost fill -- was measured and rejected: the three extra loads and FMAs in
+// k_step's row loop cost 6 % of its time at 4096^2 (11 % with a 2-D gap), more than the launch they save.
 // ---------------------------------------------------------------------------------------------
 struct GhostArgs {
     const double* qa; const double* qb;
     const double* topo; const double* Ls;
     const double* seam[2];      // per x edge: [2 rows][4: h,hx,hy,Ls][pitch] = topography of (source row, its
                                 // upwind row) on the far side of a periodic slab seam, or nullptr
-    double* g1x; double* g1y;   // (A', R') pairs [6][pitch], [6][Nx+2]
+    double* g1x; double* g1y;   // finished ghost values [3][pitch], [3][Nx+2]
     const StepState* st;
     Layout L; Edges E;
     int honor_stop;
@@ -289,28 +287,6 @@ struct StoredField {
     const double* q; Layout L;
     __device__ __forceinline__ double get(int ix, int iy, int c) const { return q[c * L.plane + L.at(ix, iy)]; }
 };
-// The interior of a freshly written field with its physical ghost cells derived on the fly by the ghost rules
-// (x rule, then y rule: the reference's order, so corners agree) -- what k_ghost_fill's fill blocks are writing
-// while its prepass blocks read.
-struct FilledField {
-    const double* q; Layout L; Edges E;
-    __device__ __forceinline__ double get(int ix, int iy, int c) const {
-        int sx = ix, sy = iy, ex = -1, ey = -1;
-        if (ix == 0 || ix == L.Nx + 1) {
-            ex = ix == 0 ? 0 : 1;
-            sx = E.rule[ex][0] == BC_P ? (ex == 0 ? L.Nx : 1) : (ex == 0 ? 1 : L.Nx);
-        }
-        if (iy == 0 || iy == L.Ny + 1) {
-            ey = iy == 0 ? 2 : 3;
-            sy = E.rule[ey][0] == BC_P ? (ey == 2 ? L.Ny : 1) : (ey == 2 ? 1 : L.Ny);
-        }
-        double v = q[c * L.plane + L.at(sx, sy)];
-        if (ex >= 0) v = ghost_rule(E, ex, c, v);
-        if (ey >= 0) v = ghost_rule(E, ey, c, v);
-        return v;
-    }
-};
-
 // A slab's field whose two outer rows are still in this rank's mailbox (peer-to-peer transport): what StoredField
 // will show once the rows have been scattered.
 struct MailField {
@@ -376,8 +352,7 @@ __device__ __forceinline__ Stage1Item stage1_item(const GhostArgs& a, int D, int
 // One tile of 64 work items by a 256-thread block.  The three closures of an item are evaluated by three different
 // WAVES (wave 0: source cell, wave 1: x-upwind, wave 2: y-upwind; wave 3 idles), which cuts the dependent arithmetic
 // chain of this latency-bound job to a third; the upwind fluxes travel through LDS.
-// FINAL: dt is known, store (rule(q - dt R), 0); otherwise store the dt-independent pair (s q + t, s R).
-template <int EOS, bool HAS_LS, bool FINAL, class Field>
+template <int EOS, bool HAS_LS, class Field>
 __device__ __forceinline__ void ghost_stage1_tile(const Field& fld, const GhostArgs& a, const Phys& P, int D, int t0, double dt,
                                                   double (*sm)[3][64]) {
     const Layout& L = a.L;
@@ -420,22 +395,12 @@ __device__ __forceinline__ void ghost_stage1_tile(const Field& fld, const GhostA
         R[2] = cx * (f.fx2 - sm[0][2][lane]) + cy * (f.fy2 - sm[1][2][lane]) - f.s2;
         double* g = it.row ? a.g1x : a.g1y;
         const int stride = it.row ? L.pitch : L.Nx + 2;
-        for (int k = 0; k < 3; ++k) {
-            const int o = k * stride + it.out;
-            if (FINAL) {
-                g[o] = ghost_rule(a.E, it.edge, k, A[k] - dt * R[k]);
-                g[o + 3 * stride] = 0.0;
-            } else {
-                g[o] = ghost_rule(a.E, it.edge, k, A[k]);
-                g[o + 3 * stride] = a.E.rule[it.edge][k] == BC_D ? -R[k] : R[k];
-            }
-        }
+        for (int k = 0; k < 3; ++k) g[k * stride + it.out] = ghost_rule(a.E, it.edge, k, A[k] - dt * R[k]);
     }
     __syncthreads();                // the LDS tile is free again
 }
 
-// stage-1 ghost data of the step about to run, from the stored field (ghost cells and halo rows included): after an
-// upload, and at the start of every step of a slab on the all-gather transport
+// stage-1 ghost data of the step about to run, from the stored field (ghost cells and halo rows included)
 template <int EOS, bool HAS_LS>
 __global__ __launch_bounds__(256) void k_ghost_stage1(const GhostArgs a, const Phys P) {
     __shared__ double sm[2][3][64];
@@ -446,7 +411,7 @@ __global__ __launch_bounds__(256) void k_ghost_stage1(const GhostArgs a, const P
     const int D = predictor_direction(a.st);
     const double dt = a.st->dt;
     const int ntiles = (L.Ny + L.Nx + 63) / 64;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) ghost_stage1_tile<EOS, HAS_LS, true>(fld, a, P, D, tile * 64, dt, sm);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) ghost_stage1_tile<EOS, HAS_LS>(fld, a, P, D, tile * 64, dt, sm);
 }
 
 }  // namespace gpf
