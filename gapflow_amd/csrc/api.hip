@@ -237,9 +237,9 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
     make_phys(*cfg, h->P);
 
     // strips of the fused step; the split of the rows into chunks is fitted to the kernel's residency
-    // on first use (plan_step), at most max_chunks of >= 8 rows
+    // on first use (plan_step), at most max_chunks of >= 2 rows
     h->nstrips = (L.Ny + STRIP - 1) / STRIP;
-    h->max_chunks = std::max(1, (L.Nx + 7) / 8);
+    h->max_chunks = std::max(1, (L.Nx + 1) / 2);
     h->npartials = h->nstrips * h->max_chunks;
 
     const size_t plane_b = (size_t)L.plane * sizeof(double);
@@ -613,7 +613,7 @@ static int plan_step(gpf_handle* h) {
         const int want_chunks = std::max(1, resident / blocks_per_chunk);
         rows = (L.Nx + want_chunks - 1) / want_chunks;
     }
-    rows = std::max(8, std::min(rows, L.Nx));
+    rows = std::max(std::getenv("GPF_ROWS_PER_CHUNK") ? 2 : 8, std::min(rows, L.Nx));
     if (rows > L.Nx) rows = L.Nx;
     h->rows_per_chunk = std::min(rows, std::max(L.Nx, 1));
     h->nchunks = (L.Nx + h->rows_per_chunk - 1) / h->rows_per_chunk;
