@@ -262,8 +262,8 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
     HIP_TRY_C(hipMalloc(&h->st, sizeof(StepState)));
     HIP_TRY_C(hipMemset(h->st, 0, sizeof(StepState)));
     h->nghost_blocks = std::max(1, std::min(64, (2 * (L.Ny + 2) + 2 * L.Nx + 255) / 256));
-    HIP_TRY_C(hipMalloc(&h->partials, (size_t)(h->npartials + h->nghost_blocks) * sizeof(Partial)));
-    HIP_TRY_C(hipMemset(h->partials, 0, (size_t)(h->npartials + h->nghost_blocks) * sizeof(Partial)));
+    HIP_TRY_C(hipMalloc(&h->partials, (size_t)h->npartials * sizeof(Partial)));
+    HIP_TRY_C(hipMemset(h->partials, 0, (size_t)h->npartials * sizeof(Partial)));
     HIP_TRY_C(hipMalloc(&h->arrive, 2 * sizeof(unsigned int)));
     HIP_TRY_C(hipMemset(h->arrive, 0, 2 * sizeof(unsigned int)));
     HIP_TRY_C(hipMalloc(&h->block_partials, 1024 * sizeof(Partial)));
@@ -656,14 +656,14 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     g.st = h->st; g.L = L; g.E = h->E; g.honor_stop = honor_stop;
     const bool slab = slab_out != nullptr;
     FinishArgs f;
-    f.partials = h->partials; f.npartials = np_step + h->nghost_blocks; f.st = h->st;
+    f.partials = h->partials; f.st = h->st;
     f.log = h->log; f.log_base = log_base; f.log_cap = h->log_cap; f.out = slab_out; f.honor_stop = honor_stop;
     f.L = L; f.E = h->E;
     f.p2p = p2p_args(h, p2p);
     f.arrive = h->arrive; f.msg = slab ? h->halo : nullptr;
     f.nstep_partials = np_step; f.block_partials = h->block_partials;
     GhostFillArgs gf;
-    gf.qa = h->q[0]; gf.qb = h->q[1]; gf.st = h->st; gf.partials = h->partials + np_step;
+    gf.qa = h->q[0]; gf.qb = h->q[1]; gf.st = h->st;
     gf.L = L; gf.E = h->E; gf.honor_stop = honor_stop;
 
     // Launches per step:

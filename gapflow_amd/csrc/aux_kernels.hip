@@ -221,13 +221,13 @@ struct P2PArgs {
 };
 
 struct FinishArgs {
-    const Partial* partials; int npartials;
+    const Partial* partials;    // k_step's per-wave records (nstep_partials of them)
     StepState* st;
     LogEntry* log; long long log_base, log_cap;
     double* out;            // if non-null: slab mode, write the 8-double local record here instead of committing
     int honor_stop;
     Layout L; Edges E;
-    int nstep_partials;     // the first nstep_partials records come from k_step, the rest from the fill blocks
+    int nstep_partials;
     Partial* block_partials;// one record per block of the edge kernel (its slice of k_step's records)
     unsigned int* arrive;   // blocks of the edge kernel that are done (reset by the last one)
     double* msg;            // slab, all-gather transport: [first row | last row] of the local message
@@ -360,7 +360,6 @@ __device__ inline void send_rows_block(const double* q, const FinishArgs& f, int
 struct GhostFillArgs {
     double* qa; double* qb;
     const StepState* st;
-    Partial* partials;      // gridDim.x records, behind the step kernel's
     Layout L; Edges E;
     int honor_stop;
 };

@@ -7,7 +7,7 @@ csrc/step_kernel.hip), so per time step each rank needs ONE row from each neighb
 (sum Ekin, max v^2, max c^2, validity).  Both travel in a single all-gather after the stencil
 kernel, before the dt/residual commit:
 
-    gpf_step_local   (prepass + fused stencil + local ghost rules + message: first row, last row, record)
+    gpf_step_local   (stage-1 ghost data + fused stencil + local ghost rules + message: first row, last row, record)
     all_gather_into_tensor(gathered, message)               <- torch.distributed (RCCL over xGMI)
     gpf_step_commit  (scatter the neighbours' rows, reduce records in rank order, advance dt/residual)
 

@@ -140,7 +140,7 @@ int gpf_step(gpf_handle* h, int64_t n, int honor_stop, gpf_scalars_t* log, int64
              int64_t* n_executed);
 /* Measurement aid: n updates with a HIP event pair around each launch of the fused step kernel
  * (recorded on the handle's stream).  *kernel_ms = sum of the n kernel durations, *total_ms =
- * elapsed device time of the whole sequence (prepass + step + finish kernels). */
+ * elapsed device time of the whole sequence (stage-1 ghost data, fused step, ghost fill with the commit). */
 int gpf_step_timed(gpf_handle* h, int64_t n, double* kernel_ms, double* total_ms);
 /* The reference-ordered, unfused stage pipeline (closures -> flux -> source -> axpy -> ghost),
  * one kernel per reference function; same results as gpf_step(h,1,...).  Kept for
@@ -157,7 +157,7 @@ int gpf_set_dt(gpf_handle* h, double dt);
  * row is 3 components x the padded row and the record is [sum Ekin, max v^2, max c^2 (NaN as +inf), invalid flags,
  * 0...].  The address is fixed for the life of the handle (usable as an RCCL / torch.distributed buffer).
  *
- * gpf_step_local : ghost-stage prepass + fused stencil + local ghost rules + the message.
+ * gpf_step_local : stage-1 ghost data + fused stencil + local ghost rules + the message.
  * (caller)       : all-gather the messages of all slabs, rank order, into `gathered` (device, nranks * count).
  * gpf_step_commit: scatter the neighbours' rows into rows ix=0 / ix=Nx+1 (rank_lo: the rank whose LAST row is my
  *                  row 0, rank_hi: the rank whose FIRST row is my row Nx+1, -1 = physical edge), reduce the records
