@@ -184,3 +184,27 @@ def test_reference_module_paths_exist():
     import gapflow_amd.md as md
     with pytest.raises(NotImplementedError):
         md.LennardJones
+
+
+def test_argument_errors_are_reported_not_crashed():
+    """Error convention of the C ABI (0 or a negative gpf_status, message in gpf_last_error): bad arguments are
+    rejected before any device work, so this runs without a GPU."""
+    from gapflow_amd import _lib
+    lib = _lib.load()
+    a = (ctypes.c_double * 64)()
+    P = ctypes.c_void_p
+    INVALID = -1
+    assert lib.gpf_predictor_corrector(0, 4, a, a, a, 1, a, a) == INVALID
+    assert lib.gpf_source(4, 4, a, a, a, a, None, a) == INVALID
+    assert lib.gpf_viscous_stress(4, a, a, None, None, a, a, 0.1, 0., 0., 0, None, None, None) == INVALID     # no output
+    assert b'no output' in lib.gpf_last_error()
+    assert lib.gpf_viscous_stress(0, a, a, None, None, a, a, 0.1, 0., 0., 0, a, None, None) == INVALID
+    assert lib.gpf_eos(99, a, 4, a, a, None) == INVALID and b'unknown equation of state' in lib.gpf_last_error()
+    assert lib.gpf_eos(0, a, 4, a, None, None) == INVALID
+    assert lib.gpf_viscosity(7, 0, a, 0.1, 4, a, None, None, 0., 0., a) == INVALID
+    assert lib.gpf_viscosity(0, 99, a, 0.1, 4, a, None, None, 0., 0., a) == INVALID and b'unknown law' in lib.gpf_last_error()
+    # handle-taking entry points refuse a null handle
+    for name, args in (('gpf_step_p2p', (None, 1, 0)), ('gpf_p2p_export', (None, a, 64)), ('gpf_stage_message', (None,)),
+                       ('gpf_close_step_local', (None,)), ('gpf_step_local', (None, 0))):
+        assert getattr(lib, name)(*args) < 0, name
+    assert lib.gpf_destroy(None) == 0
