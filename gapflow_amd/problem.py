@@ -116,26 +116,26 @@ class Problem:
     # constructors (problem.py:211-308)
     # -------------------------------------------------------------------------------------
     @classmethod
-    def from_yaml(cls, fname):
+    def from_yaml(cls, fname, device=0):
         print(f"Reading input file: {fname}")
         with open(fname, "r") as f:
-            return cls._from_dict(read_yaml_input(f))
+            return cls._from_dict(read_yaml_input(f), device=device)
 
     @classmethod
-    def from_string(cls, ymlstring):
+    def from_string(cls, ymlstring, device=0):
         with _io.StringIO(ymlstring) as f:
-            return cls._from_dict(read_yaml_input(f))
+            return cls._from_dict(read_yaml_input(f), device=device)
 
     @classmethod
-    def _from_dict(cls, input_dict):
+    def _from_dict(cls, input_dict, device=0):
         gp = input_dict.get('gp', None)
         db = input_dict.get('db', None)
         database = None
         if db is not None:
             from .gp import make_database
-            database = make_database(input_dict)
+            database = make_database(input_dict, device)
         return cls(input_dict['options'], input_dict['grid'], input_dict['numerics'], input_dict['properties'],
-                   input_dict['geometry'], gp=gp, database=database, extra_field=None)
+                   input_dict['geometry'], gp=gp, database=database, extra_field=None, device=device)
 
     # -------------------------------------------------------------------------------------
     # configuration -> C struct

@@ -200,6 +200,7 @@ class SlabProblem:
         if dist is None:
             import torch.distributed as dist
         self.torch, self.dist = torch, dist
+        self._device, self._writer_problem = device, None
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.input = input_dict
         grid, prop, geo = input_dict['grid'], input_dict['properties'], input_dict['geometry']
@@ -407,6 +408,89 @@ class SlabProblem:
         if sc.invalid == 3:
             raise RuntimeError("slab step: a peer rank did not deliver its rows within 30 s (peer-to-peer transport)")
         return sc
+
+    # -- Problem.run for slabs -----------------------------------------------------------------
+    def gather_q(self):
+        """The whole field (3, Nx+2, Ny+2) on every rank: owned rows from their owners, the domain's two ghost rows
+        from the first and last rank.  Collective; meant for output frames, not for the time loop."""
+        t, L = self.torch, self.layout
+        parts = partition(L.Nx_global, self.world)
+        max_nx = max(hi - lo + 1 for lo, hi in parts)
+        ny2 = self._shape[1]
+        mine = np.zeros((3, max_nx + 2, ny2))
+        mine[:, :L.nx + 2] = self.local_q()
+        send = t.from_numpy(mine.reshape(-1)).to('cuda')
+        recv = t.zeros(send.numel() * self.world, dtype=t.float64, device='cuda')
+        self.dist.all_gather_into_tensor(recv, send)
+        allq = recv.cpu().numpy().reshape(self.world, 3, max_nx + 2, ny2)
+        out = np.empty((3, L.Nx_global + 2, ny2))
+        for r, (lo, hi) in enumerate(parts):
+            out[:, lo:hi + 1] = allq[r, :, 1:hi - lo + 2]
+        out[:, 0] = allq[0, :, 0]
+        out[:, -1] = allq[-1, :, parts[-1][1] - parts[-1][0] + 2]
+        return out
+
+    def _frame(self):
+        """One output frame through a whole-domain Problem that only rank 0 holds: it owns the output directory, the
+        NetCDF / csv writers and the closures of the frame (Problem.write, problem.py:616-637)."""
+        q = self.gather_q()
+        if self.rank != 0:
+            return
+        if self._writer_problem is None:
+            from .problem import Problem
+            d = deepcopy(self.input)
+            self._writer_problem = Problem(d['options'], d['grid'], d['numerics'], d['properties'], d['geometry'],
+                                           device=self._device)
+            w = self._writer_problem
+            w.history = {k: [] for k in ('step', 'time', 'ekin', 'residual', 'vsound')}
+        w = self._writer_problem
+        st = self.state()
+        w.q[...] = q
+        w.step, w.simtime, w.dt, w.residual = int(st.step), st.simtime, st.dt, st.residual
+        w.write(params=False)
+
+    def run(self):
+        """Problem.run (problem.py:368-410) for a slab-decomposed problem: same stopping rules (tolerance on the last
+        five residuals, max_it, invalid state), same status lines and output files, written by rank 0."""
+        import datetime as _dt
+        opt, num = self.input['options'], self.input['numerics']
+        silent, wf, max_it = opt['silent'], opt['write_freq'], num['max_it']
+        if self._gp_models and not silent:
+            raise NotImplementedError("output frames of a slab run with surrogate closures: set options.silent")
+        self.pre_run()
+        if not silent:
+            if self.rank == 0:
+                print(61 * '-')
+                print(f"{'Step':6s} {'Timestep':10s} {'Time':10s} {'CFL':10s} {'Residual':10s}")
+                print(61 * '-')
+            self._frame()
+        tic = _dt.datetime.now()
+        st = self.state()
+        while not st.converged and st.step < max_it and not st.invalid:
+            n = min(wf - st.step % wf, max_it - st.step, 4096)
+            self.advance(n, honor_stop=True)
+            st = self.state()
+            if st.invalid:
+                if self.rank == 0:
+                    print('NaN detected.' if st.invalid == 1 else 'Negative density detected.',
+                          'Writing previous step and aborting simulation.')
+                break
+            if st.step % wf == 0 and not silent:
+                self._frame()
+        if not silent and st.step % wf != 0:
+            self._frame()
+        if self.rank == 0:
+            wall = _dt.datetime.now() - tic
+            print(33 * '=')
+            print("Total walltime   : ", str(wall).split('.')[0])
+            print(f"({st.step / max(wall.total_seconds(), 1e-12):.2f} steps/s)")
+            print(33 * '=')
+            if not silent:
+                from .io import history_to_csv
+                w = self._writer_problem
+                w._writer.close()
+                history_to_csv(os.path.join(w.outdir, 'history.csv'), w.history)
+        return st
 
     def local_q(self):
         out = np.empty((3,) + self._shape)

@@ -190,3 +190,59 @@ def test_multi_rank_gp_closures_match_serial(hiplib, tmp_path, text, world):
         np.testing.assert_allclose(z['dt'], serial.dt, rtol=1e-10)
         np.testing.assert_allclose(z['ekin'], serial.kinetic_energy, rtol=1e-10)
         np.testing.assert_allclose(z['residual'], serial.residual, rtol=1e-5, atol=1e-10)
+
+
+def _slab_run_worker(rank, world, port, text, p2p):
+    import torch
+    import torch.distributed as dist
+    from gapflow_amd.slab import SlabProblem
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        slab = SlabProblem.from_string(text, device=0, dist=StagedGloo(dist, torch))
+        if p2p:
+            assert slab.connect_p2p()
+        st = slab.run()
+        assert st.step == 45 and st.invalid == 0
+    finally:
+        dist.destroy_process_group()
+
+
+RUN_SIM = """
+options: {{output: {out}, write_freq: 20, use_tstamp: False, silent: False}}
+grid: {{Nx: 150, Ny: 70, dx: 1.e-5, dy: 1.e-5}}
+geometry: {{type: journal, CR: 1.e-2, eps: 0.7, U: 0.1, V: 0.02}}
+numerics: {{CFL: 0.5, adaptive: 1, MC_order: 0, tol: 1.e-12, max_it: 45}}
+properties: {{EOS: DH, shear: 0.0794, bulk: 0., rho0: 877.7007}}
+"""
+
+
+@pytest.mark.parametrize('p2p', [False, True], ids=['allgather', 'p2p'])
+def test_slab_run_writes_the_same_files_as_the_serial_run(hiplib, tmp_path, p2p):
+    """SlabProblem.run(): frames at write_freq and at the end, history.csv, config.yml -- by rank 0, equal to
+    Problem.run() on the same input."""
+    import csv
+    import torch.multiprocessing as mp
+    from scipy.io import netcdf_file
+    from gapflow_amd import Problem
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_slab_run_worker, args=(3, port, RUN_SIM.format(out=str(tmp_path / 'slab')), p2p), nprocs=3, join=True)
+    Problem.from_string(RUN_SIM.format(out=str(tmp_path / 'serial'))).run()
+    for f in ('config.yml', 'history.csv', 'sol.nc', 'topo.nc'):
+        assert (tmp_path / 'slab' / f).exists(), f
+    rows = [list(csv.reader(open(tmp_path / d / 'history.csv'))) for d in ('slab', 'serial')]
+    assert rows[0][0] == rows[1][0] and len(rows[0]) == len(rows[1]) == 5          # header + steps 0, 20, 40, 45
+    a, b = (np.array(r[1:], float) for r in rows)
+    np.testing.assert_array_equal(a[:, 0], [0, 20, 40, 45])
+    np.testing.assert_allclose(a[:, 1:3], b[:, 1:3], rtol=1e-11)                  # time, ekin
+    np.testing.assert_allclose(a[:, 3], b[:, 3], rtol=1e-5, atol=1e-12)            # residual (difference of near-equal sums)
+    np.testing.assert_allclose(a[:, 4], b[:, 4], rtol=1e-11)                      # vsound
+    with netcdf_file(str(tmp_path / 'slab' / 'sol.nc'), mmap=False) as fa, netcdf_file(str(tmp_path / 'serial' / 'sol.nc'), mmap=False) as fb:
+        for name in ('solution', 'pressure'):
+            va, vb = fa.variables[name][:], fb.variables[name][:]
+            assert va.shape == vb.shape and va.shape[0] == 4
+            assert np.abs(va - vb).max() <= 1e-11 * np.abs(vb).max(), name
