@@ -204,6 +204,9 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
     if (!cfg || !out) return fail(GPF_ERR_INVALID, "gpf_create: null argument");
     if (cfg->Nx < 1 || cfg->Ny < 1) return fail(GPF_ERR_INVALID, "gpf_create: Nx, Ny must be >= 1");
     if (!(cfg->dx > 0) || !(cfg->dy > 0)) return fail(GPF_ERR_INVALID, "gpf_create: dx, dy must be > 0");
+    // the kernels index cells of one plane with 32-bit offsets (a 46000^2 grid would still fit the card's memory)
+    if (((long long)cfg->Nx + 2) * ((long long)cfg->Ny + 2 + 64) > 2000000000ll)
+        return fail(GPF_ERR_INVALID, "gpf_create: more than 2e9 cells per plane; cut the domain into x-slabs (gapflow_amd/slab.py)");
     if (cfg->eos < GPF_EOS_DH || cfg->eos > GPF_EOS_BAYADA) return fail(GPF_ERR_INVALID, "gpf_create: unknown EOS id");
     if (cfg->thinning < 0 || cfg->thinning > GPF_THINNING_CARREAU) return fail(GPF_ERR_INVALID, "gpf_create: unknown shear-thinning id");
     for (int e = 0; e < 4; ++e) {

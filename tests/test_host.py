@@ -208,3 +208,12 @@ def test_argument_errors_are_reported_not_crashed():
                        ('gpf_close_step_local', (None,)), ('gpf_step_local', (None, 0))):
         assert getattr(lib, name)(*args) < 0, name
     assert lib.gpf_destroy(None) == 0
+
+
+def test_grid_beyond_32_bit_offsets_is_refused():
+    from gapflow_amd import _lib
+    lib = _lib.load()
+    cfg = _lib.GpfConfig()
+    cfg.Nx, cfg.Ny, cfg.dx, cfg.dy = 50000, 50000, 1e-5, 1e-5
+    h = ctypes.c_void_p()
+    assert lib.gpf_create(ctypes.byref(cfg), ctypes.byref(h)) == -1 and b'2e9 cells' in lib.gpf_last_error()
