@@ -200,7 +200,7 @@ class SlabProblem:
         if dist is None:
             import torch.distributed as dist
         self.torch, self.dist = torch, dist
-        self._device, self._writer_problem = device, None
+        self._device, self._writer_problem, self._pre_run_done = device, None, False
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.input = input_dict
         grid, prop, geo = input_dict['grid'], input_dict['properties'], input_dict['geometry']
@@ -358,6 +358,7 @@ class SlabProblem:
         dt = num['CFL'] * dt_crit if num['adaptive'] else num['dt']
         _lib.check(self.lib.gpf_set_dt(self._h, float(dt)))
         _lib.check(self.lib.gpf_set_ekin_old(self._h, float(g['ekin'])))
+        self._pre_run_done = True
 
     def advance(self, n, honor_stop=False, write_freq=None):
         if not self._gp_models:
@@ -457,7 +458,8 @@ class SlabProblem:
         silent, wf, max_it = opt['silent'], opt['write_freq'], num['max_it']
         if self._gp_models and not silent:
             raise NotImplementedError("output frames of a slab run with surrogate closures: set options.silent")
-        self.pre_run()
+        if not self._pre_run_done:
+            self.pre_run()
         if not silent:
             if self.rank == 0:
                 print(61 * '-')
