@@ -60,8 +60,8 @@ struct gpf_handle {
     double* halo = nullptr;                 // this slab's all-gather message: first row, last row (3 x pitch each), 8-double record
     StepState* st = nullptr;
     Partial* partials = nullptr;
-    unsigned int* arrive = nullptr;         // [0] blocks of k_ghost_fill that are done (finish_step), [1] same for k_begin_p2p
-    bool g1_ready = false;                  // g1 already holds the next step's stage-1 ghost values (k_begin_p2p wrote them)
+    unsigned int* arrive = nullptr;         // [0] blocks of k_ghost_fill that are done (finish_step), [1] same for k_begin_slab
+    bool g1_ready = false;                  // g1 already holds the next step's stage-1 ghost values (k_begin_slab wrote them)
     Partial* block_partials = nullptr;      // one record per edge-kernel block
     int npartials = 0, nstrips = 0, nchunks = 0, rows_per_chunk = 0, nghost_blocks = 0;
     ScalarPartial* spart = nullptr;         // k_scalars block records (+ 4 totals at the end)
@@ -633,6 +633,21 @@ static P2PArgs p2p_args(gpf_handle* h, bool on) {
     return c;
 }
 
+static int ghost_args(gpf_handle* h, int honor_stop, GhostArgs& g) {
+    const Layout& L = h->L;
+    g.qa = h->q[0]; g.qb = h->q[1]; g.topo = h->topo; g.Ls = h->Ls;
+    for (int e = 0; e < 2; ++e) {
+        g.seam[e] = nullptr;
+        if (h->E.halo[e] == 2) {
+            if (!h->has_seam[e]) return fail(GPF_ERR_STATE, "periodic slab seam: call gpf_set_seam_topo for this edge first");
+            g.seam[e] = h->seam + (size_t)e * 8 * L.pitch;
+        }
+    }
+    g.g1x = h->g1; g.g1y = h->g1 + 3 * L.pitch;
+    g.st = h->st; g.L = L; g.E = h->E; g.honor_stop = honor_stop;
+    return GPF_OK;
+}
+
 static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, double* slab_out,
                         hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, bool p2p = false) {
     const Layout& L = h->L;
@@ -647,16 +662,7 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     a.st = h->st; a.partials = h->partials; a.L = L; a.E = h->E;
     a.rows_per_chunk = h->rows_per_chunk; a.nstrips = h->nstrips; a.honor_stop = honor_stop;
     GhostArgs g;
-    g.qa = h->q[0]; g.qb = h->q[1]; g.topo = h->topo; g.Ls = h->Ls;
-    for (int e = 0; e < 2; ++e) {
-        g.seam[e] = nullptr;
-        if (h->E.halo[e] == 2) {
-            if (!h->has_seam[e]) return fail(GPF_ERR_STATE, "periodic slab seam: call gpf_set_seam_topo for this edge first");
-            g.seam[e] = h->seam + (size_t)e * 8 * L.pitch;
-        }
-    }
-    g.g1x = h->g1; g.g1y = h->g1 + 3 * L.pitch;
-    g.st = h->st; g.L = L; g.E = h->E; g.honor_stop = honor_stop;
+    GPF_TRY(ghost_args(h, honor_stop, g));
     const bool slab = slab_out != nullptr;
     FinishArgs f;
     f.partials = h->partials; f.st = h->st;
@@ -674,7 +680,7 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     //   k_step          the fused predictor + corrector + average over the interior
     //   k_ghost_fill    ghost cells of the new field (+ a slab's boundary rows into its message / its peers'
     //                   mailboxes); its last block to finish reduces all records and commits dt, residual, step
-    //   peer-to-peer slabs: k_begin_p2p (wait for the peers' rows and records, commit, k_ghost_stage1's job for the
+    //   peer-to-peer slabs: k_begin_slab (wait for the peers' rows and records, commit, k_ghost_stage1's job for the
     //                   next step) takes the place of the next step's k_ghost_stage1
     const int ntiles = (L.Nx + L.Ny + 63) / 64;                 // stage-1 ghost work: 64 items per block
     const dim3 ggrid(std::min(ntiles, 512)), sgrid((h->nstrips + 3) / 4, h->nchunks);
@@ -683,6 +689,7 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     WaitArgs w;
     w.qa = h->q[0]; w.qb = h->q[1]; w.st = h->st; w.log = h->log; w.log_base = log_base; w.log_cap = h->log_cap;
     w.L = L; w.E = h->E; w.honor_stop = honor_stop; w.arrive = h->arrive + 1; w.p2p = f.p2p;
+    w.gathered = nullptr; w.msg_len = 0; w.nranks = 0; w.rank_lo = w.rank_hi = -1;
     const bool has_ls = h->Ls != nullptr;
     EOS_DISPATCH(h->cfg.eos, {
         if (!h->g1_ready) {
@@ -694,11 +701,11 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
         if (ev1) hipEventRecord(ev1, h->stream);
         hipLaunchKernelGGL((k_ghost_fill<EOS_>), dim3(h->nghost_blocks + nsend), dim3(256), 0, h->stream, gf, f, h->nghost_blocks, h->P);
         if (p2p) {                          // wait for the peers, commit, stage-1 ghost data of the next step
-            if (has_ls) hipLaunchKernelGGL((k_begin_p2p<EOS_, true>), ggrid, dim3(256), 0, h->stream, g, w, h->P);
-            else hipLaunchKernelGGL((k_begin_p2p<EOS_, false>), ggrid, dim3(256), 0, h->stream, g, w, h->P);
+            if (has_ls) hipLaunchKernelGGL((k_begin_slab<EOS_, true, true>), ggrid, dim3(256), 0, h->stream, g, w, h->P);
+            else hipLaunchKernelGGL((k_begin_slab<EOS_, false, true>), ggrid, dim3(256), 0, h->stream, g, w, h->P);
         }
     });
-    h->g1_ready = p2p;                  // k_begin_p2p has prepared the next step's ghost data
+    h->g1_ready = p2p;                  // k_begin_slab has prepared the next step's ghost data
     HIP_TRY(hipGetLastError());
     return GPF_OK;
 }
@@ -1007,12 +1014,22 @@ extern "C" int gpf_step_commit(gpf_handle* h, int honor_stop, const void* gather
     if (rank_lo >= nranks || rank_hi >= nranks) return fail(GPF_ERR_INVALID, "gpf_step_commit: neighbour rank out of range");
     if (!h->halo) return fail(GPF_ERR_STATE, "gpf_step_commit without gpf_step_local");
     HIP_TRY(hipSetDevice(h->cfg.device));
-    hipLaunchKernelGGL(k_halo_unpack, dim3((h->L.pitch + 255) / 256), dim3(256), 0, h->stream,
-                       halo_args(h, honor_stop, (const double*)gathered, rank_lo, rank_hi));
-    hipLaunchKernelGGL(k_commit_gathered, dim3(1), dim3(1), 0, h->stream, h->st, (const double*)gathered,
-                       (long long)halo_len(h), (long long)6 * h->L.pitch, nranks, h->log, (long long)h->host_step,
-                       (long long)h->log_cap, honor_stop);
+    // one launch: scatter the neighbours' rows, reduce the records in rank order, commit, and prepare the next step's
+    // stage-1 ghost data (so the next gpf_step_local starts with the stencil)
+    const Layout& L = h->L;
+    GhostArgs g;
+    GPF_TRY(ghost_args(h, honor_stop, g));
+    WaitArgs w;
+    w.qa = h->q[0]; w.qb = h->q[1]; w.st = h->st; w.log = h->log; w.log_base = h->host_step; w.log_cap = h->log_cap;
+    w.L = L; w.E = h->E; w.honor_stop = honor_stop; w.arrive = h->arrive + 1; w.p2p = p2p_args(h, false);
+    w.gathered = (const double*)gathered; w.msg_len = (long long)halo_len(h); w.nranks = nranks; w.rank_lo = rank_lo; w.rank_hi = rank_hi;
+    const dim3 ggrid(std::min((L.Nx + L.Ny + 63) / 64, 512));
+    EOS_DISPATCH(h->cfg.eos, {
+        if (h->Ls) hipLaunchKernelGGL((k_begin_slab<EOS_, true, false>), ggrid, dim3(256), 0, h->stream, g, w, h->P);
+        else hipLaunchKernelGGL((k_begin_slab<EOS_, false, false>), ggrid, dim3(256), 0, h->stream, g, w, h->P);
+    });
     HIP_TRY(hipGetLastError());
+    h->g1_ready = true;
     return GPF_OK;
 }
 

@@ -458,7 +458,7 @@ __global__ void k_halo_unpack(const HaloArgs a) {
     }
 }
 
-// Receiving side of the peer-to-peer transport, fused with the start of the NEXT step.  Every block waits (bounded)
+// Receiving side of a slab step (either transport), fused with the start of the NEXT step.  Every block waits (bounded)
 // for message seq+1 of every rank in this rank's own mailbox, works out what the commit will decide -- the same
 // rank-ordered reduction of the records, the same dt -- scatters its share of the two neighbour rows into the outer
 // rows and computes its share of the next step's stage-1 ghost values (reading the outer rows from the mailbox, since
@@ -472,21 +472,27 @@ struct WaitArgs {
     Layout L; Edges E;
     int honor_stop;
     unsigned int* arrive;
-    P2PArgs p2p;
+    P2PArgs p2p;                // MAILBOX source: rank ids, mailboxes, message counter
+    const double* gathered;     // all-gather source: nranks messages [first row | last row | record] of msg_len doubles
+    long long msg_len;
+    int nranks, rank_lo, rank_hi;
 };
-template <int EOS, bool HAS_LS>
-__global__ __launch_bounds__(256) void k_begin_p2p(const GhostArgs g, const WaitArgs a, const Phys P) {
+// MAILBOX: rows and records are waited for in this rank's mailbox (peer-to-peer transport); otherwise they are read from
+// the buffer an all-gather has filled before this launch (same layout as gpf_slab_message, rank order).
+template <int EOS, bool HAS_LS, bool MAILBOX>
+__global__ __launch_bounds__(256) void k_begin_slab(const GhostArgs g, const WaitArgs a, const Phys P) {
     __shared__ int missing, last;
     __shared__ double tiles[2][3][64];
     StepState* st = a.st;
     if (st->invalid != 0 || (a.honor_stop && (st->converged || st->step >= st->max_it))) return;
     const P2PArgs& c = a.p2p;
-    const unsigned long long n = *c.seq + 1;
+    const unsigned long long n = MAILBOX ? *c.seq + 1 : 0ull;
     const int slot = (int)(n & 1);
-    MailHeader* hd = (MailHeader*)c.box[c.rank];
+    MailHeader* hd = MAILBOX ? (MailHeader*)c.box[c.rank] : nullptr;
+    const int nranks = MAILBOX ? c.nranks : a.nranks, rank_lo = MAILBOX ? c.rank_lo : a.rank_lo, rank_hi = MAILBOX ? c.rank_hi : a.rank_hi;
     if (threadIdx.x == 0) missing = 0;
     __syncthreads();
-    if (threadIdx.x < c.nranks) {
+    if (MAILBOX && threadIdx.x < c.nranks) {
         const long long t0 = wall_clock64();
         bool ok = false;
         int probes = 0;
@@ -508,8 +514,9 @@ __global__ __launch_bounds__(256) void k_begin_p2p(const GhostArgs g, const Wait
     // what the commit will decide (identical in every block and on every rank)
     double ekin = 0.0, v2 = 0.0, c2 = 0.0;
     int flags = 0;
-    for (int r = 0; r < c.nranks; ++r) {
-        const double* p = hd->rec[slot][r];
+    const Layout& L = a.L;
+    for (int r = 0; r < nranks; ++r) {
+        const double* p = MAILBOX ? hd->rec[slot][r] : a.gathered + r * a.msg_len + 6ll * L.pitch;
         ekin += p[0];
         v2 = fmax(v2, p[1]); c2 = fmax(c2, p[2]);
         flags |= (int)p[3];
@@ -517,12 +524,14 @@ __global__ __launch_bounds__(256) void k_begin_p2p(const GhostArgs g, const Wait
     const double inf = __builtin_inf();
     if (v2 == inf) v2 = __builtin_nan("");
     if (c2 == inf) c2 = __builtin_nan("");
-    const Layout& L = a.L;
     const int nblocks = gridDim.x * gridDim.y, block = blockIdx.y * gridDim.x + blockIdx.x;
     if ((flags & 3) == 0) {
         double* q = st->parity ? a.qa : a.qb;           // the field the step has produced (current after the commit)
-        const double* row_lo = (c.rank_lo >= 0 && a.E.halo[0]) ? p2p_rows(c.box[c.rank], slot, 0, L.pitch) : nullptr;
-        const double* row_hi = (c.rank_hi >= 0 && a.E.halo[1]) ? p2p_rows(c.box[c.rank], slot, 1, L.pitch) : nullptr;
+        // my row 0 is the lower neighbour's LAST row, my row Nx+1 the upper neighbour's FIRST row
+        const double* row_lo = !(rank_lo >= 0 && a.E.halo[0]) ? nullptr
+                             : MAILBOX ? p2p_rows(c.box[c.rank], slot, 0, L.pitch) : a.gathered + rank_lo * a.msg_len + 3ll * L.pitch;
+        const double* row_hi = !(rank_hi >= 0 && a.E.halo[1]) ? nullptr
+                             : MAILBOX ? p2p_rows(c.box[c.rank], slot, 1, L.pitch) : a.gathered + rank_hi * a.msg_len;
         for (int t = block * blockDim.x + threadIdx.x; t < 6 * L.pitch; t += nblocks * blockDim.x) {
             const int side = t / (3 * L.pitch), k = (t / L.pitch) % 3, i = t % L.pitch;
             const double* src = side ? row_hi : row_lo;
@@ -543,7 +552,7 @@ __global__ __launch_bounds__(256) void k_begin_p2p(const GhostArgs g, const Wait
     __syncthreads();
     if (last && threadIdx.x == 0) {
         __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *c.seq = n;
+        if (MAILBOX) *c.seq = n;
         commit_step(st, ekin, v2, c2, flags, a.log, a.log_base, a.log_cap);
     }
 }
