@@ -265,8 +265,8 @@ __global__ __launch_bounds__(256) void k_step(const StepArgs a, const Phys P) {
 //   Neumann  : q1(ghost) = q1(adjacent)                (problem.py:766)
 //   Dirichlet: q1(ghost) = 2*target - q1(adjacent)     (problem.py:758-764)
 // q1 at the source cell is the ordinary predictor result there: q1 = q - dt R.  k_step reads finished ghost values
-// g1 = rule(q - dt R), written at the start of every step by k_ghost_stage1 (or, for slabs on the peer-to-peer
-// transport, by the previous step's k_begin_p2p).  Handing k_step the dt-independent pair (rule-folded q, R) instead --
+// g1 = rule(q - dt R), written at the start of every step by k_ghost_stage1 (or, for slabs, by the previous step's
+// k_begin_slab once the neighbours' rows are in).  Handing k_step the dt-independent pair (rule-folded q, R) instead --
 // prepared one launch earlier, inside the ghost fill -- was measured and rejected: the three extra loads and FMAs in
 // k_step's row loop cost 6 % of its time at 4096^2 (11 % with a 2-D gap), more than the launch they save.
 // ---------------------------------------------------------------------------------------------
