@@ -106,7 +106,8 @@ def _outdir(tmp_path):
 
 
 @pytest.mark.parametrize('name,text', [('inclined_1d_powerlaw', INCLINED_PL), ('journal_1d_dowson-higginson', JOURNAL_DH),
-                                       ('parabolic_1d_cav_bayada', PARABOLIC_BAYADA)])
+                                       ('parabolic_1d_cav_bayada', PARABOLIC_BAYADA)],
+                         ids=['inclined_1d_powerlaw', 'journal_1d_dowson-higginson', 'parabolic_1d_cav_bayada'])
 def test_fixed_form_examples_run(hiplib, tmp_path, name, text):
     from gapflow_amd import Problem
     prob = Problem.from_string(text.format(out=str(tmp_path / name)))
@@ -126,7 +127,8 @@ def test_fixed_form_examples_run(hiplib, tmp_path, name, text):
 
 
 @pytest.mark.parametrize('name,text,dim', [('journal_1d_gp', JOURNAL_1D_GP, 1), ('journal_2d_gp', JOURNAL_2D_GP, 2),
-                                           ('parabolic_1d_lj_gp', PARABOLIC_LJ_GP, 1), ('asperity_2d_lj_gp', ASPERITY_LJ_GP, 2)])
+                                           ('parabolic_1d_lj_gp', PARABOLIC_LJ_GP, 1), ('asperity_2d_lj_gp', ASPERITY_LJ_GP, 2)],
+                         ids=['journal_1d_gp', 'journal_2d_gp', 'parabolic_1d_lj_gp', 'asperity_2d_lj_gp'])
 def test_surrogate_examples_run(hiplib, tmp_path, name, text, dim):
     """`db:` without `md:` attaches the Mock runner (problem.py:232-243); active learning defaults to True (io.py:416)."""
     from gapflow_amd import Problem

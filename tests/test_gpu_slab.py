@@ -113,7 +113,8 @@ properties: {EOS: DH, shear: 0.0794, bulk: 0., rho0: 877.7007}
 
 
 @pytest.mark.parametrize('p2p', [False, True], ids=['allgather', 'p2p'])
-@pytest.mark.parametrize('text,world', [(SIM, 2), (SIM, 3), (DIRICHLET, 2), (DIRICHLET, 3)])
+@pytest.mark.parametrize('text,world', [(SIM, 2), (SIM, 3), (DIRICHLET, 2), (DIRICHLET, 3)],
+                         ids=['periodic-2', 'periodic-3', 'dirichlet-2', 'dirichlet-3'])
 def test_multi_rank_engine_matches_serial(hiplib, tmp_path, text, world, p2p):
     """2 and 3 processes sharing this GPU, each owning an x-slab: assembled result == the one-handle run.
     `p2p`: rows and records travel through IPC-mapped mailboxes written and polled by the step's own kernels
@@ -162,7 +163,8 @@ GP_PERIODIC = GP_SIM.replace("xE: ['D', 'N', 'N'], xW: ['D', 'N', 'N'], xE_D: 87
 
 
 @pytest.mark.parametrize('text,world', [(GP_SIM.replace('AL_PRESS', 'False'), 2), (GP_SIM.replace('AL_PRESS', 'True'), 3),
-                                        (GP_PERIODIC.replace('AL_PRESS', 'False'), 2)])
+                                        (GP_PERIODIC.replace('AL_PRESS', 'False'), 2)],
+                         ids=['dirichlet-2', 'dirichlet-active-learning-3', 'periodic-2'])
 def test_multi_rank_gp_closures_match_serial(hiplib, tmp_path, text, world):
     """Surrogate closures across slabs (stage-wise step, rows exchanged after each stage, replicated database,
     domain-wide active learning) against the one-handle Problem.update() on the same input."""
