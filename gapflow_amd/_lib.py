@@ -32,8 +32,9 @@ THINNING_KEYS = {'Eyring': ['tauE'], 'Carreau': ['mu_inf', 'lam', 'a', 'N']}
 BC_P, BC_D, BC_N = 0, 1, 2
 FIELD_Q, FIELD_TOPO, FIELD_EXTRA, FIELD_PRESSURE, FIELD_TAU_AVG, FIELD_WALL_LOWER, FIELD_WALL_UPPER = range(7)
 FIELD_PRESSURE_VAR, FIELD_WALL_XZ_VAR, FIELD_WALL_YZ_VAR = 7, 8, 9
+FIELD_DEFORMATION = 10
 FIELD_NCOMP = {FIELD_Q: 3, FIELD_TOPO: 3, FIELD_EXTRA: 1, FIELD_PRESSURE: 1, FIELD_TAU_AVG: 3,
-               FIELD_WALL_LOWER: 6, FIELD_WALL_UPPER: 6, 7: 1, 8: 1, 9: 1}
+               FIELD_WALL_LOWER: 6, FIELD_WALL_UPPER: 6, 7: 1, 8: 1, 9: 1, 10: 1}
 
 
 class GpfConfig(C.Structure):
@@ -81,6 +82,8 @@ SIGNATURES = {
     'gpf_eos': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     'gpf_viscosity': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_double, C.c_double, C.c_void_p]),
+    'gpf_elastic_setup': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_int]),
+    'gpf_elastic_update': (C.c_int, [C.c_void_p]),
     'gpf_p2p_export': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     'gpf_p2p_connect': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     'gpf_step_p2p': (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
@@ -120,9 +123,10 @@ def _pin_hip_runtime():
     if os.environ.get('GPF_SYSTEM_HIP') == '1':
         return
     if 'torch' in sys.modules:
-        blas = os.path.join(os.path.dirname(sys.modules['torch'].__file__), 'lib', 'librocblas.so')
-        if os.path.exists(blas):
-            os.environ.setdefault('GPF_ROCBLAS_PATH', blas)
+        libdir = os.path.join(os.path.dirname(sys.modules['torch'].__file__), 'lib')
+        for var, name in (('GPF_ROCBLAS_PATH', 'librocblas.so'), ('GPF_HIPFFT_PATH', 'libhipfft.so')):
+            if os.path.exists(os.path.join(libdir, name)):
+                os.environ.setdefault(var, os.path.join(libdir, name))
         return
     try:
         import importlib.util
@@ -136,9 +140,9 @@ def _pin_hip_runtime():
     if os.path.exists(cand):
         C.CDLL(cand, mode=C.RTLD_GLOBAL)
         # rocBLAS (GP variance solve) must come from the same bundle, or a later `import torch` crashes
-        blas = os.path.join(libdir, 'librocblas.so')
-        if os.path.exists(blas):
-            os.environ.setdefault('GPF_ROCBLAS_PATH', blas)
+        for var, name in (('GPF_ROCBLAS_PATH', 'librocblas.so'), ('GPF_HIPFFT_PATH', 'libhipfft.so')):
+            if os.path.exists(os.path.join(libdir, name)):
+                os.environ.setdefault(var, os.path.join(libdir, name))
 
 
 def load():

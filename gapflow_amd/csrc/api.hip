@@ -12,6 +12,7 @@
 #include "step_kernel.hip"
 #include "aux_kernels.hip"
 #include "gp_kernels.hip"
+#include "elastic_kernels.hip"
 
 using namespace gpf;
 
@@ -83,6 +84,10 @@ struct gpf_handle {
     double* gpvar = nullptr;                // 3 variance planes
     double* gpscratch = nullptr;            // block maxima + 4 result slots
     int gpscratch_n = 0;
+    // elastic half-space (gpf_elastic_*): transform grid, Green's function in Fourier space, work buffers, state planes
+    struct { bool on = false; int px = 0, py = 0, relative = 0; double alpha = 1.0, scale = 1.0; void* plan_f = nullptr; void* plan_b = nullptr;
+             double2* greens = nullptr; double2* spec = nullptr; double* dense = nullptr;
+             double* u_prev = nullptr; double* h0 = nullptr; double* deformation = nullptr; } el;
     double* gptile = nullptr;               // Ks tile for the variance solve
     size_t gptile_doubles = 0;
     void* blas = nullptr;
@@ -288,6 +293,10 @@ extern "C" int gpf_destroy(gpf_handle* h) {
                     h->gp[0].Z, h->gp[0].alpha, h->gp[0].L, h->gp[1].Z, h->gp[1].alpha, h->gp[1].L,
                     h->gp[2].Z, h->gp[2].alpha, h->gp[2].L};
     if (h->blas && roclibs().ok) roclibs().destroy(h->blas);
+    if (h->el.plan_f) fftlib().destroy(h->el.plan_f);
+    if (h->el.plan_b) fftlib().destroy(h->el.plan_b);
+    for (void* p : {(void*)h->el.greens, (void*)h->el.spec, (void*)h->el.dense, (void*)h->el.u_prev})     // h0, deformation live in u_prev's block
+        if (p) hipFree(p);
     for (int r = 0; r < h->p2p.nranks; ++r)
         if (h->p2p.box[r] && r != h->p2p.rank) hipIpcCloseMemHandle(h->p2p.box[r]);
     if (h->p2p.mine) hipFree(h->p2p.mine);
@@ -315,6 +324,7 @@ static int field_ncomp(int field) {
     case GPF_FIELD_WALL_LOWER: return 6;
     case GPF_FIELD_WALL_UPPER: return 6;
     case GPF_FIELD_PRESSURE_VAR: case GPF_FIELD_WALL_XZ_VAR: case GPF_FIELD_WALL_YZ_VAR: return 1;
+    case GPF_FIELD_DEFORMATION: return 1;
     }
     return 0;
 }
@@ -373,7 +383,7 @@ extern "C" int gpf_upload(gpf_handle* h, int field, const double* host, size_t c
             }
         const int mode = xonly ? 1 : (yonly ? 2 : 0);
         if (mode != h->topo_mode) h->plan_valid = false;
-        h->topo_mode = mode;
+        h->topo_mode = h->el.on ? 0 : mode;         // an elastic gap changes on the device: always read the planes
         if (mode) {
             const int n = mode == 1 ? nx : ny;
             std::vector<double> line((size_t)3 * n);
@@ -415,6 +425,9 @@ extern "C" int gpf_download(gpf_handle* h, int field, double* host, size_t count
     case GPF_FIELD_EXTRA:
         if (!h->Ls) { std::memset(host, 0, count * sizeof(double)); return GPF_OK; }
         src = h->Ls; break;
+    case GPF_FIELD_DEFORMATION:
+        if (!h->el.on) { std::memset(host, 0, count * sizeof(double)); return GPF_OK; }
+        src = h->el.deformation; break;
     case GPF_FIELD_PRESSURE_VAR: case GPF_FIELD_WALL_XZ_VAR: case GPF_FIELD_WALL_YZ_VAR:
         if (!h->gpvar) return fail(GPF_ERR_STATE, "gpf_download: no GP variance has been computed");
         src = h->gpvar + (size_t)(field - GPF_FIELD_PRESSURE_VAR) * L.plane;
@@ -1030,6 +1043,65 @@ extern "C" int gpf_step_commit(gpf_handle* h, int honor_stop, const void* gather
     });
     HIP_TRY(hipGetLastError());
     h->g1_ready = true;
+    return GPF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// elastic deformation of the gap (topography.py:257-280, 327-437)
+// ---------------------------------------------------------------------------------------------
+extern "C" int gpf_elastic_setup(gpf_handle* h, int px, int py, const double* greens_ri, size_t count, double alpha,
+                                 double force_scale, int relative) {
+    if (!h || !greens_ri) return fail(GPF_ERR_INVALID, "gpf_elastic_setup: null argument");
+    const Layout& L = h->L;
+    if (px < L.Nx + 2 || py < L.Ny + 2) return fail(GPF_ERR_INVALID, "gpf_elastic_setup: the transform grid must hold the field incl. ghost cells");
+    const size_t nspec = (size_t)px * (py / 2 + 1);
+    if (count != 2 * nspec) return fail(GPF_ERR_INVALID, "gpf_elastic_setup: count must be 2 * px * (py/2 + 1) (real, imaginary)");
+    if (!h->has_topo) return fail(GPF_ERR_STATE, "gpf_elastic_setup: upload the undeformed topography first");
+    if (h->E.halo[0] || h->E.halo[1]) return fail(GPF_ERR_STATE, "gpf_elastic_setup: not available for slabs (the half-space couples the whole domain)");
+    FftLib& F = fftlib();
+    if (!F.ok) return fail(GPF_ERR_SOLVER, F.err);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    auto& e = h->el;
+    if (e.on) return fail(GPF_ERR_STATE, "gpf_elastic_setup: already set up");
+    HIP_TRY(hipMalloc((void**)&e.greens, nspec * sizeof(double2)));
+    HIP_TRY(hipMalloc((void**)&e.spec, nspec * sizeof(double2)));
+    HIP_TRY(hipMalloc((void**)&e.dense, (size_t)px * py * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&e.u_prev, (size_t)3 * L.plane * sizeof(double)));
+    e.h0 = e.u_prev + L.plane; e.deformation = e.u_prev + 2 * L.plane;
+    HIP_TRY(hipMemset(e.u_prev, 0, (size_t)3 * L.plane * sizeof(double)));
+    HIP_TRY(hipMemcpy(e.greens, greens_ri, nspec * sizeof(double2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e.h0, h->topo, (size_t)L.plane * sizeof(double), hipMemcpyDeviceToDevice));
+    if (F.plan2d(&e.plan_f, px, py, HIPFFT_D2Z_) != 0 || F.plan2d(&e.plan_b, px, py, HIPFFT_Z2D_) != 0)
+        return fail(GPF_ERR_SOLVER, "hipfftPlan2d failed");
+    e.px = px; e.py = py; e.alpha = alpha; e.relative = relative ? 1 : 0;
+    e.scale = force_scale / ((double)px * (double)py);      // hipFFT's inverse is unnormalised
+    e.on = true;
+    h->topo_mode = 0;                                       // the gap now changes every step: read the planes
+    return GPF_OK;
+}
+
+// Topography.update + update_gradients with the pressure of the last closure evaluation (problem.py:566 uses the
+// stored field, i.e. stage 2's): h, dh/dx, dh/dy of the handle change in place.
+extern "C" int gpf_elastic_update(gpf_handle* h) {
+    if (!h) return fail(GPF_ERR_INVALID, "gpf_elastic_update: null handle");
+    auto& e = h->el;
+    if (!e.on) return fail(GPF_ERR_STATE, "gpf_elastic_update: call gpf_elastic_setup first");
+    if (!h->fields) return fail(GPF_ERR_STATE, "gpf_elastic_update: no pressure field yet (gpf_stage_closures / gpf_update_closures)");
+    FftLib& F = fftlib();
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const Layout& L = h->L;
+    const long long nd = (long long)e.px * e.py, ns = (long long)e.px * (e.py / 2 + 1), nc = (long long)(L.Nx + 2) * (L.Ny + 2);
+    F.set_stream(e.plan_f, h->stream); F.set_stream(e.plan_b, h->stream);
+    hipLaunchKernelGGL(k_el_pack, dim3(blocks_for(nd)), dim3(256), 0, h->stream, h->fields, L, e.px, e.py, e.relative, e.dense);
+    if (F.d2z(e.plan_f, e.dense, e.spec) != 0) return fail(GPF_ERR_SOLVER, "hipfftExecD2Z failed");
+    hipLaunchKernelGGL(k_el_multiply, dim3(blocks_for(ns)), dim3(256), 0, h->stream, e.spec, e.greens, ns);
+    if (F.z2d(e.plan_b, e.spec, e.dense) != 0) return fail(GPF_ERR_SOLVER, "hipfftExecZ2D failed");
+    hipLaunchKernelGGL(k_el_relax, dim3(blocks_for(nc)), dim3(256), 0, h->stream, e.dense, e.py, e.scale, e.alpha, L, e.u_prev);
+    hipLaunchKernelGGL(k_el_apply, dim3(blocks_for(nc)), dim3(256), 0, h->stream, e.u_prev, e.h0, e.relative, L, e.deformation, h->topo);
+    hipLaunchKernelGGL(k_el_gradient, dim3(blocks_for(nc)), dim3(256), 0, h->stream, h->topo, L, 1.0 / h->cfg.dx, 1.0 / h->cfg.dy,
+                       h->topo + L.plane, h->topo + 2 * L.plane);
+    HIP_TRY(hipGetLastError());
+    h->g1_ready = false;
     return GPF_OK;
 }
 

@@ -22,11 +22,18 @@ class FieldWriter:
     def __init__(self, problem):
         self._p = problem
         nx, ny = problem._shape
+        # without elastic deformation the topography is written once and closed; with it a frame is appended with every
+        # solution frame (problem.py:183-190, 636-637)
         topo = netcdf_file(os.path.join(problem.outdir, 'topo.nc'), 'w', version=2)
         self._dims(topo, nx, ny, {'tensor_dim__topography-0': 4})
         v = topo.createVariable('topography', 'f8', ('frame', 'tensor_dim__topography-0', 'subpt__1', 'nx', 'ny'))
         v[0] = problem.topo.full[:, None]
-        topo.close()
+        self._topo_file, self._topo_var, self._ntopo = None, None, 1
+        if problem.topo.elastic:
+            self._topo_file, self._topo_var = topo, v
+            topo.flush()
+        else:
+            topo.close()
         self._f = netcdf_file(os.path.join(problem.outdir, 'sol.nc'), 'w', version=2)
         self._dims(self._f, nx, ny, {'tensor_dim__solution-0': 3, 'tensor_dim__wall_stress-0': 12})
         self._sol = self._f.createVariable('solution', 'f8', ('frame', 'tensor_dim__solution-0', 'subpt__1', 'nx', 'ny'))
@@ -53,8 +60,15 @@ class FieldWriter:
         self._wyz[k] = p.wall_stress_yz.full[:, None]
         self._n += 1
         self._f.flush()
+        if self._topo_file is not None:
+            self._topo_var[self._ntopo] = p.topo.full[:, None]
+            self._ntopo += 1
+            self._topo_file.flush()
 
     def close(self):
         if self._f is not None:
             self._f.close()
             self._f = None
+        if self._topo_file is not None:
+            self._topo_file.close()
+            self._topo_file = None

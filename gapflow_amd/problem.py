@@ -73,6 +73,13 @@ class Problem:
 
         self.topo = Topography(grid, geo, prop, on_change=self._upload_topo)
         self._upload_topo()
+        self._elastic = None
+        if self.topo.elastic:                   # topography.py:236-249
+            from .elastic import ElasticDeformation
+            el = prop['elastic']
+            self._elastic = ElasticDeformation(el['E'], el['v'], el['alpha_underrelax'], grid, el['n_images'])
+            self._elastic.attach(self)
+            self.topo.refresh = self._download_topo
 
         self._closures_stale = True
         self.database = database
@@ -225,6 +232,11 @@ class Problem:
         self._upload(_lib.FIELD_TOPO, self.topo.full[:3])
         self._closures_stale = True
 
+    def _download_topo(self, field):
+        """Host mirror of the deformed gap: h, dh/dx, dh/dy and the displacement (topography.py:283-305)."""
+        field[:3] = self._download(_lib.FIELD_TOPO, 3)
+        field[3] = self._download(_lib.FIELD_DEFORMATION, 1)[0]
+
     def _sync_to_device(self):
         """Push user edits of ``q`` before any device operation."""
         if self._q_snapshot is not None and not self._device_newer:
@@ -369,8 +381,8 @@ class Problem:
         """One MacCormack predictor-corrector time step (problem.py:509-569), on the device."""
         if self.step is None:
             raise RuntimeError("call _pre_run() (or run()) before update()")
-        if self._gp_models or self._cfg.thinning:
-            self._update_with_surrogates()      # stage-wise pipeline (host between stages / grad p for thinning)
+        if self._gp_models or self._cfg.thinning or self._elastic:
+            self._update_with_surrogates()      # stage-wise pipeline (host between stages / grad p for thinning / elastic gap)
         else:
             self._advance(1, honor_stop=False)
 
@@ -404,6 +416,12 @@ class Problem:
         if sc.invalid:
             self._finalize(sc.invalid)
             return
+        if self._elastic:
+            # Topography.update (problem.py:566): the gap deforms under the pressure of the last closure evaluation
+            # (the corrector's), on the device; the host mirror of the topography is refreshed on access
+            _lib.check(lib.gpf_elastic_update(h))
+            self.topo.mark_stale()
+            self._closures_stale = True
         self._absorb([sc])
         self._mark_device_advanced()
 
@@ -434,7 +452,7 @@ class Problem:
         self._tic = datetime.now()
         wf = self.options['write_freq']
         try:
-            while (self._gp_models or self._cfg.thinning) and not self.converged and self.step < self.max_it and not self._stop:
+            while (self._gp_models or self._cfg.thinning or self._elastic) and not self.converged and self.step < self.max_it and not self._stop:
                 self.update()                   # surrogates: one host-driven step at a time
                 if self.step % wf == 0 and not silent and not self._stop:
                     self.write()

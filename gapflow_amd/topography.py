@@ -1,7 +1,7 @@
 """Gap topography: analytic height profiles and their slopes on the cell-centre grid.
 
 Host-side set-up code (runs once per problem); mirrors GaPFlow/topography.py:38-324.  The
-elastic half-space coupling (topography.py:327-465, ContactMechanics FFT) is out of scope.
+elastic half-space coupling (topography.py:327-465) lives in gapflow_amd/elastic.py and on the device.
 """
 import numpy as np
 
@@ -89,13 +89,14 @@ class Topography:
     ``full[:3]`` once (topography.py:180-255)."""
 
     def __init__(self, grid, geo, prop, on_change=None):
-        if prop.get('elastic', {}).get('enabled', False):
-            raise NotImplementedError("elastic deformation (GaPFlow/topography.py:327-465) is outside the "
-                                      "scope of the MI355X hot path")
         xx, yy = create_midpoint_grid(grid)
         self._x, self._y = xx, yy
         self.dx, self.dy = grid['dx'], grid['dy']
-        self.elastic = False
+        # with elastic deformation the device owns h, dh/dx, dh/dy and the displacement after the first update; the host
+        # arrays are then a mirror that `refresh` (set by the Problem) brings up to date on access
+        self.elastic = bool(prop.get('elastic', {}).get('enabled', False))
+        self.refresh = None
+        self._stale = False
         if geo['type'] in _PROFILES_1D:
             h, dh_dx, dh_dy = _PROFILES_1D[geo['type']](xx, grid, geo)
         elif geo['type'] == 'asperity':
@@ -110,7 +111,16 @@ class Topography:
         self._on_change = on_change
 
     def update(self):
-        """No-op without elastic deformation (topography.py:257-271)."""
+        """Topography.update of the reference (topography.py:257-271) happens on the device (gpf_elastic_update, called
+        by Problem.update); nothing to do on the host."""
+
+    def mark_stale(self):
+        self._stale = True
+
+    def _sync(self):
+        if self._stale and self.refresh is not None:
+            self._stale = False
+            self.refresh(self._field)
 
     def update_gradients(self):
         # topography.py:273-280: second-order central differences, one-sided at the array edges
@@ -121,10 +131,12 @@ class Topography:
 
     @property
     def full(self):
+        self._sync()
         return self._field
 
     @property
     def h(self):
+        self._sync()
         return self._field[0]
 
     @h.setter
@@ -134,14 +146,17 @@ class Topography:
 
     @property
     def deformation(self):
+        self._sync()
         return self._field[3]
 
     @property
     def dh_dx(self):
+        self._sync()
         return self._field[1]
 
     @property
     def dh_dy(self):
+        self._sync()
         return self._field[2]
 
     @property

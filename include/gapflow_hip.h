@@ -64,7 +64,8 @@ enum {
     GPF_FIELD_WALL_UPPER = 6, /* 6 comps Voigt (problem.py:554-555)                             */
     GPF_FIELD_PRESSURE_VAR = 7,   /* GP predictive variances (stress.py:97, 499), 1 comp each         */
     GPF_FIELD_WALL_XZ_VAR = 8,
-    GPF_FIELD_WALL_YZ_VAR = 9
+    GPF_FIELD_WALL_YZ_VAR = 9,
+    GPF_FIELD_DEFORMATION = 10  /* 1: elastic displacement added to the undeformed gap height (download only) */
 };
 
 /*
@@ -166,6 +167,19 @@ int gpf_set_dt(gpf_handle* h, double dt);
 int gpf_slab_message(gpf_handle* h, void** message, size_t* count);
 int gpf_step_local(gpf_handle* h, int honor_stop);
 int gpf_step_commit(gpf_handle* h, int honor_stop, const void* gathered, int nranks, int rank_lo, int rank_hi);
+/* Elastic deformation of the gap under the film pressure (Topography.update, topography.py:257-280; ElasticDeformation,
+ * topography.py:327-437).  gpf_elastic_setup receives the half-space Green's function in Fourier space on a px x py
+ * transform grid (px >= Nx+2, py >= Ny+2; doubled along non-periodic axes), as numpy's rfft2 lays it out:
+ * greens_ri[px][py/2+1][2] (real, imaginary), count = 2 px (py/2+1); alpha = under-relaxation factor; force_scale =
+ * (force per cell / pressure) / (cell area the Green's function is normalised to); relative != 0: pressure and
+ * displacement are taken relative to cell [0, 0] (every case but the fully periodic one).  The handle's current
+ * topography is kept as the undeformed one.  gpf_elastic_update convolves the pressure of the last closure evaluation,
+ * under-relaxes, and rewrites h, dh/dx, dh/dy (np.gradient stencil) in place; GPF_FIELD_DEFORMATION downloads the
+ * displacement.  Undivided problems only. */
+int gpf_elastic_setup(gpf_handle* h, int px, int py, const double* greens_ri, size_t count, double alpha,
+                      double force_scale, int relative);
+int gpf_elastic_update(gpf_handle* h);
+
 /* Peer-to-peer slab transport (GPUs of one node, one process each).  Instead of a collective library the step's own
  * kernels store the two boundary rows and the 64-byte record straight into the peers' mailboxes (device memory mapped
  * through HIP IPC, xGMI underneath) and the receiving kernel polls a sequence flag -- no host and no extra launches

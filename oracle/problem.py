@@ -40,6 +40,13 @@ class OracleProblem:
         self.wall_lower = np.zeros((6,) + shape)    # = wall_stress_xz.lower + wall_stress_yz.lower
         self.wall_upper = np.zeros((6,) + shape)
         self.gp_models = None                       # set by oracle.gp when a surrogate is attached
+        self.elastic = None                         # topography.py:236-249
+        el = prop.get('elastic', {})
+        if el.get('enabled', False):
+            from .elastic import ElasticDeformation
+            self.elastic = ElasticDeformation(el['E'], el['v'], el['alpha_underrelax'], grid, el['n_images'])
+            self.h_undeformed = self.topo[0].copy()
+            self.deformation = np.zeros(shape)
         self.step = None
         self.kinetic_energy_old = self.kinetic_energy
         self._stop = False
@@ -164,6 +171,11 @@ class OracleProblem:
             self.stage(d, dt, predictor=(i == 0), compute_var=one_before_output)
         self.q[...] = (self.q + q0) / 2.0
         if self.q_is_valid:
+            if self.elastic is not None:            # Topography.update, problem.py:566, with the STORED pressure (stage 2's)
+                self.deformation = self.elastic.update(self.pressure)
+                self.topo[0] = self.h_undeformed + self.deformation
+                self.topo[1] = np.gradient(self.topo[0], axis=0) / self.grid['dx']      # topography.py:273-280
+                self.topo[2] = np.gradient(self.topo[0], axis=1) / self.grid['dy']
             self._post_update()
         else:                                       # problem.py:588-610
             self.q[...] = q0

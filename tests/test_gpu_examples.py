@@ -4,8 +4,8 @@ to the GPU box); `max_it` is cut so that each case takes seconds.  What is asser
 needs: the input is accepted with the reference's defaults, run() completes, fields stay finite, the output files
 and the history have the reference's shape, and the surrogate cases train / extend their database.
 
-LAMMPS-driven examples (journal_1d_gold-hexadecane_gp_lammps, parabolic_1d_lj_gp_lammps) and the elastic one
-(parabolic_1d_elastic) are out of scope."""
+LAMMPS-driven examples (journal_1d_gold-hexadecane_gp_lammps, parabolic_1d_lj_gp_lammps) are out of scope (DESIGN.md
+section 7); the elastic one (parabolic_1d_elastic) runs in tests/test_gpu_elastic.py."""
 import io
 import os
 

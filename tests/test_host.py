@@ -98,8 +98,31 @@ def test_topography_profiles_and_gradient_stencil():
     xx = par.x
     exact = 2 * (4. / grid['Lx']**2) * (xx - grid['Lx'] / 2.)
     np.testing.assert_allclose(par.dh_dx[1:-1], exact[1:-1], atol=1e-12)
-    with pytest.raises(NotImplementedError):
-        gtopo.Topography(grid, {'type': 'journal', 'CR': 1e-2, 'eps': 0.5, 'flip': False}, {'elastic': {'enabled': True}})
+    el = gtopo.Topography(grid, {'type': 'journal', 'CR': 1e-2, 'eps': 0.5, 'flip': False}, {'elastic': {'enabled': True}})
+    assert el.elastic and np.all(el.deformation == 0)       # the device takes over after the first elastic update
+
+
+def test_elastic_green_functions_match_the_oracle_restatement():
+    """gapflow_amd/elastic.py (product, host set-up) against oracle/elastic.py for every half-space variant, incl. the
+    1-D line-contact rule (topography.py:366-380).  Both restate published forms; the oracle is pinned to analytic
+    solutions in tests/test_oracle_elastic.py."""
+    import warnings
+    from gapflow_amd.elastic import ElasticDeformation
+    from oracle.elastic import ElasticDeformation as Oracle
+
+    def grid(Nx, Ny, perX, perY):
+        g = {'Nx': Nx, 'Ny': Ny, 'Lx': 3e-4, 'Ly': 2e-4, 'dx': 3e-4 / Nx, 'dy': 2e-4 / Ny}
+        for side, per in (('xE', perX), ('xW', perX), ('yS', perY), ('yN', perY)):
+            g[f'bc_{side}_P'] = [per] * 3
+        return g
+    for Nx, Ny, perX, perY in ((12, 8, True, True), (12, 8, False, False), (12, 8, False, True), (12, 8, True, False), (20, 1, False, True)):
+        g = grid(Nx, Ny, perX, perY)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            a, b = ElasticDeformation(50e9, 0.3, 0.1, g, 4), Oracle(50e9, 0.3, 0.1, g, 4)
+        assert a.periodicity == b.periodicity and a.shape_fft == b.pad
+        np.testing.assert_allclose(a.greens, b.greens, rtol=1e-13, atol=1e-30)
+        assert a.area_per_pt == b.area_per_pt
 
 
 def test_edge_rules_resolution():
