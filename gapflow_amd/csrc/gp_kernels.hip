@@ -277,6 +277,12 @@ __global__ void k_gp_logdet(const double* Lm, int n, double* out) {
 }
 
 // zero the strict upper triangle so L can be handed out as a clean lower-triangular matrix
+// n x n identity, column-major
+__global__ void k_gp_identity(double* I, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (i < n) I[i + (long long)j * n] = i == j ? 1.0 : 0.0;
+}
+
 __global__ void k_gp_clean_lower(double* Lm, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
     if (i < n && i < j) Lm[i + (long long)j * n] = 0.0;
@@ -292,8 +298,9 @@ struct RocLibs {
     typedef int (*potrf_t)(void*, int, int, double*, int, int*);
     typedef int (*potrs_t)(void*, int, int, int, double*, int, double*, int);
     typedef int (*trsm_t)(void*, int, int, int, int, int, int, const double*, const double*, int, double*, int);
+    typedef int (*gemm_t)(void*, int, int, int, int, int, const double*, const double*, int, const double*, int, const double*, double*, int);
     create_t create = nullptr; destroy_t destroy = nullptr; set_stream_t set_stream = nullptr;
-    potrf_t potrf = nullptr; potrs_t potrs = nullptr; trsm_t trsm = nullptr;
+    potrf_t potrf = nullptr; potrs_t potrs = nullptr; trsm_t trsm = nullptr; gemm_t gemm = nullptr;
     bool ok = false;
     const char* err = "";
 };
@@ -316,6 +323,7 @@ inline RocLibs& roclibs() {
     R.destroy = (RocLibs::destroy_t)dlsym(hb, "rocblas_destroy_handle");
     R.set_stream = (RocLibs::set_stream_t)dlsym(hb, "rocblas_set_stream");
     R.trsm = (RocLibs::trsm_t)dlsym(hb, "rocblas_dtrsm");
+    R.gemm = (RocLibs::gemm_t)dlsym(hb, "rocblas_dgemm");
     R.ok = R.create && R.destroy && R.set_stream && R.trsm;
     if (!R.ok) { R.err = "rocBLAS symbols missing"; return R; }
     const char* use = getenv("GPF_USE_ROCSOLVER");
