@@ -1447,7 +1447,7 @@ extern "C" int gpf_gp_variance(gpf_handle* h, int which, int on_open_step, doubl
         h->gptile_doubles = (size_t)(tile * n) * 2;
     }
     double* vtile = h->gptile + (size_t)(tile * n);
-    const int nb_total = (int)((ncell + 255) / 256) + 8;
+    const int nb_total = (int)((ncell + GP_VAR_COLS - 1) / GP_VAR_COLS) + (int)((ncell + tile - 1) / tile) + 8;
     GPF_TRY(gp_scratch(h, nb_total));
     GpFieldArgs a = gp_field_args(h, which, q);
     double* var_plane = h->gpvar + (size_t)which * L.plane;
@@ -1468,8 +1468,8 @@ extern "C" int gpf_gp_variance(gpf_handle* h, int which, int on_open_step, doubl
         } else if (R.trsm(blas, ROC_SIDE_LEFT, ROC_FILL_LOWER, ROC_OP_NONE, ROC_DIAG_NON_UNIT, n, ncols, &one, g.L, n, h->gptile, n) != 0) {
             return fail(GPF_ERR_SOLVER, "rocblas_dtrsm failed");
         }
-        const int nb = (ncols + 255) / 256;
-        hipLaunchKernelGGL(k_gp_var_tile, dim3(nb), dim3(256), 0, h->stream, v, n, ncols, g.dev.amp,
+        const int nb = (ncols + GP_VAR_COLS - 1) / GP_VAR_COLS;
+        hipLaunchKernelGGL(k_gp_var_tile, dim3(nb), dim3(1024), 0, h->stream, v, n, ncols, g.dev.amp,
                            g.dev.yscale * g.dev.yscale, c0, L, var_plane, h->gpscratch + nbm);
         HIP_TRY(hipGetLastError());
         nbm += nb;
