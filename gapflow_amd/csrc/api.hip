@@ -79,6 +79,8 @@ struct gpf_handle {
         bool set = false;
         GpModelDev dev;
         double *Z = nullptr, *alpha = nullptr, *L = nullptr, *Linv = nullptr;
+        int cap = 0;                            // training points the buffers can hold (grown in steps of 128)
+        bool has_linv = false;
         double xscale0 = 1.0;
     } gp[3];
     double* gpvar = nullptr;                // 3 variance planes
@@ -1222,14 +1224,31 @@ static int gp_factorize(void* blas, hipStream_t stream, const double* Z, int n, 
         DBG("gp_factorize: rocsolver dpotrf");
         rc = R.potrf(blas, ROC_FILL_LOWER, n, K, n, info);
         if (rc == 0) rc = R.potrs(blas, ROC_FILL_LOWER, n, m, K, n, alpha, n);
+    } else if (R.gemm && n > 96 && !getenv("GPF_GP_UNBLOCKED_POTRF")) {
+        // right-looking blocked Cholesky: 64 x 64 diagonal blocks in one workgroup, the panel solve and the trailing update
+        // on rocBLAS (dtrsm, dgemm on the matrix cores): 12 ms -> ~1 ms at n = 512
+        const int NB = 64;
+        const double one = 1.0, minus = -1.0;
+        for (int j0 = 0; j0 < n && rc == 0; j0 += NB) {
+            const int jb = std::min(NB, n - j0), rest = n - j0 - jb;
+            double* A11 = K + j0 + (long long)j0 * n;
+            hipLaunchKernelGGL(k_gp_potrf, dim3(1), dim3(1024), 0, stream, A11, jb, n, j0, info);
+            if (rest > 0) {
+                double* A21 = A11 + jb;
+                double* A22 = A21 + (long long)jb * n;
+                rc = R.trsm(blas, ROC_SIDE_RIGHT, ROC_FILL_LOWER, ROC_OP_TRANS, ROC_DIAG_NON_UNIT, rest, jb, &one, A11, n, A21, n);
+                if (rc == 0) rc = R.gemm(blas, ROC_OP_NONE, ROC_OP_TRANS, rest, rest, jb, &minus, A21, n, A21, n, &one, A22, n);
+            }
+        }
+        hipLaunchKernelGGL(k_gp_potrs, dim3(1), dim3(1024), 0, stream, K, n, m, alpha);
     } else {
-        hipLaunchKernelGGL(k_gp_potrf, dim3(1), dim3(1024), 0, stream, K, n, info);
+        hipLaunchKernelGGL(k_gp_potrf, dim3(1), dim3(1024), 0, stream, K, n, n, 0, info);
         hipLaunchKernelGGL(k_gp_potrs, dim3(1), dim3(1024), 0, stream, K, n, m, alpha);
     }
     hipError_t e = hipMemcpyAsync(info_host, info, sizeof(int), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     hipFree(info);
-    if (rc != 0) return fail(GPF_ERR_SOLVER, "rocSOLVER dpotrf/dpotrs returned status " + std::to_string(rc));
+    if (rc != 0) return fail(GPF_ERR_SOLVER, "rocBLAS / rocSOLVER returned status " + std::to_string(rc) + " in the Cholesky factorisation");
     if (e != hipSuccess) return fail(GPF_ERR_HIP, hipGetErrorString(e));
     hipLaunchKernelGGL(k_gp_clean_lower, dim3((n + 127) / 128, n), dim3(128), 0, stream, K, n);
     HIP_TRY(hipGetLastError());
@@ -1301,6 +1320,7 @@ extern "C" int gpf_gp_clear_model(gpf_handle* h, int which) {
     if (g.L) hipFree(g.L);
     if (g.Linv) hipFree(g.Linv);
     g.Z = g.alpha = g.L = g.Linv = nullptr;
+    g.cap = 0;
     g.set = false;
     return GPF_OK;
 }
@@ -1314,18 +1334,27 @@ extern "C" int gpf_gp_set_model(gpf_handle* h, int which, int n, int d, int m, c
     if (m != (which == 0 ? 1 : 2)) return fail(GPF_ERR_INVALID, "gpf_gp_set_model: pressure has 1 output, wall shear 2 (lower, upper)");
     for (int k = 0; k < d; ++k)
         if (dims[k] < 0 || dims[k] > 6) return fail(GPF_ERR_INVALID, "gpf_gp_set_model: feature index out of range 0..6");
-    GPF_TRY(gpf_gp_clear_model(h, which));
+    auto& g = h->gp[which];
+    // active learning refits after every added point: keep the buffers while they are large enough
+    if (n > g.cap) {
+        GPF_TRY(gpf_gp_clear_model(h, which));
+        const size_t cap = (size_t)((n + 127) / 128) * 128;
+        HIP_TRY(hipMalloc(&g.Z, cap * GP_MAX_D * 8));
+        HIP_TRY(hipMalloc(&g.alpha, cap * 2 * 8));
+        HIP_TRY(hipMalloc(&g.L, cap * cap * 8));
+        HIP_TRY(hipMalloc(&g.Linv, cap * cap * 8));
+        g.cap = (int)cap;
+    } else {
+        HIP_TRY(hipStreamSynchronize(h->stream));      // nothing may still read the old model
+    }
+    g.set = false;
     void* blas = nullptr;
     GPF_TRY(gp_blas(h, &blas));
-    auto& g = h->gp[which];
     std::vector<double> Z((size_t)n * d), Ycm((size_t)n * m);
     for (int i = 0; i < n; ++i) {
         for (int k = 0; k < d; ++k) Z[(size_t)i * d + k] = Xn[(size_t)i * d + k] * inv_scale[k];
         for (int o = 0; o < m; ++o) Ycm[(size_t)o * n + i] = Yn[(size_t)i * m + o];
     }
-    HIP_TRY(hipMalloc(&g.Z, Z.size() * 8));
-    HIP_TRY(hipMalloc(&g.alpha, Ycm.size() * 8));
-    HIP_TRY(hipMalloc(&g.L, (size_t)n * n * 8));
     HIP_TRY(hipMemcpyAsync(g.Z, Z.data(), Z.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(g.alpha, Ycm.data(), Ycm.size() * 8, hipMemcpyHostToDevice, h->stream));
     int info = 0;
@@ -1345,7 +1374,6 @@ extern "C" int gpf_gp_set_model(gpf_handle* h, int which, int n, int d, int m, c
     if (roclibs().gemm && !(getenv("GPF_GP_VARIANCE") && std::string(getenv("GPF_GP_VARIANCE")) == "trsm")) {
         RocLibs& R = roclibs();
         const double one = 1.0;
-        HIP_TRY(hipMalloc(&g.Linv, (size_t)n * n * 8));
         hipLaunchKernelGGL(k_gp_identity, dim3((n + 127) / 128, n), dim3(128), 0, h->stream, g.Linv, n);
         hipLaunchKernelGGL(k_gp_clean_lower, dim3((n + 127) / 128, n), dim3(128), 0, h->stream, g.L, n);
         HIP_TRY(hipGetLastError());
@@ -1353,6 +1381,9 @@ extern "C" int gpf_gp_set_model(gpf_handle* h, int which, int n, int d, int m, c
             return fail(GPF_ERR_SOLVER, "rocblas_dtrsm (inverse of the Cholesky factor) failed");
         hipLaunchKernelGGL(k_gp_clean_lower, dim3((n + 127) / 128, n), dim3(128), 0, h->stream, g.Linv, n);
         HIP_TRY(hipGetLastError());
+        g.has_linv = true;
+    } else {
+        g.has_linv = false;
     }
     g.set = true;
     if (!h->gpvar) {
@@ -1439,7 +1470,7 @@ extern "C" int gpf_gp_variance(gpf_handle* h, int which, int on_open_step, doubl
     const long long ncell = (long long)(L.Nx + 2) * (L.Ny + 2);
     const int n = g.dev.n;
     const long long tile = std::max<long long>(256, std::min<long long>(ncell, (64ll << 20) / (8ll * n)));   // <= 64 MiB of Ks
-    const bool use_gemm = g.Linv != nullptr;
+    const bool use_gemm = g.has_linv;
     if (h->gptile_doubles < (size_t)(tile * n) * 2) {        // Ks tile + the product tile
         if (h->gptile) HIP_TRY(hipFree(h->gptile));
         h->gptile = nullptr;

@@ -238,36 +238,39 @@ __global__ __launch_bounds__(1024) void k_gp_var_tile(const double* V, int n, in
 // (512^2 doubles = 2 MB).  *info = 0, or j+1 if the leading minor of order j+1 is not positive definite
 // (LAPACK dpotrf convention).  rocSOLVER's dpotrf is the alternative (GPF_USE_ROCSOLVER=1); its 930 MB
 // shared object costs ~100 s to map on a cold node, which no 45-MFLOP factorisation can repay.
-__global__ __launch_bounds__(1024) void k_gp_potrf(double* A, int n, int* info) {
+// A: n x n block with leading dimension lda, lower triangle factorised in place.  *info is written only on failure
+// (first non-positive pivot, 1-based, offset by `row0` for a diagonal block of a larger matrix) or, with row0 == 0, reset.
+__global__ __launch_bounds__(1024) void k_gp_potrf(double* A, int n, int lda, int row0, int* info) {
     __shared__ double diag;
     __shared__ int bad;
     const int tid = threadIdx.x, T = blockDim.x;
     const int tk = tid >> 5, ti = tid & 31;
     if (tid == 0) bad = 0;
+    if (row0 > 0 && *info != 0) return;             // an earlier diagonal block already failed
     for (int j = 0; j < n; ++j) {
         __syncthreads();
         if (tid == 0) {
-            double d = A[j + (long long)j * n];
-            if (!(d > 0.0)) { bad = j + 1; d = 1.0; } else d = sqrt(d);
-            A[j + (long long)j * n] = d;
+            double d = A[j + (long long)j * lda];
+            if (!(d > 0.0)) { bad = row0 + j + 1; d = 1.0; } else d = sqrt(d);
+            A[j + (long long)j * lda] = d;
             diag = d;
         }
         __syncthreads();
         if (bad) break;
         const double inv = 1.0 / diag;
-        for (int i = j + 1 + tid; i < n; i += T) A[i + (long long)j * n] *= inv;
+        for (int i = j + 1 + tid; i < n; i += T) A[i + (long long)j * lda] *= inv;
         __syncthreads();
-        const double* col = A + (long long)j * n;
+        const double* col = A + (long long)j * lda;
         for (int kk = j + 1; kk < n; kk += 32) {
             const int k = kk + tk;
             for (int ii = kk; ii < n; ii += 32) {
                 const int i = ii + ti;
-                if (k < n && i < n && i >= k) A[i + (long long)k * n] -= col[i] * col[k];
+                if (k < n && i < n && i >= k) A[i + (long long)k * lda] -= col[i] * col[k];
             }
         }
     }
     __syncthreads();
-    if (tid == 0) *info = bad;
+    if (tid == 0 && (bad || row0 == 0)) *info = bad;
 }
 
 // Solves L L^T X = B in place for nrhs right-hand sides (B column-major n x nrhs), one workgroup
@@ -330,7 +333,7 @@ struct RocLibs {
 };
 
 // rocBLAS enum values (rocblas-types.h): fill lower = 122, side left = 141, op none = 111, diag non-unit = 131
-enum { ROC_FILL_LOWER = 122, ROC_SIDE_LEFT = 141, ROC_OP_NONE = 111, ROC_DIAG_NON_UNIT = 131 };
+enum { ROC_FILL_LOWER = 122, ROC_SIDE_LEFT = 141, ROC_SIDE_RIGHT = 142, ROC_OP_NONE = 111, ROC_OP_TRANS = 112, ROC_DIAG_NON_UNIT = 131 };
 
 inline RocLibs& roclibs() {
     static RocLibs R;
