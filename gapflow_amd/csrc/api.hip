@@ -1492,9 +1492,17 @@ extern "C" int gpf_gp_variance(gpf_handle* h, int which, int on_open_step, doubl
         HIP_TRY(hipGetLastError());
         const double* v = h->gptile;
         if (use_gemm) {     // V = L^-1 Ks
+            // L^-1 is lower triangular: the upper row block needs only the first half of the columns -> 3/4 of the flops.
+            // (Four row blocks would need 10/16, but 128-row products fill only half of the CUs: measured 56 ms per pass
+            // against 40 ms with two blocks and 46 ms with one.)
             const double zero = 0.0;
-            if (R.gemm(blas, ROC_OP_NONE, ROC_OP_NONE, n, ncols, n, &one, g.Linv, n, h->gptile, n, &zero, vtile, n) != 0)
-                return fail(GPF_ERR_SOLVER, "rocblas_dgemm failed");
+            const int nblk = n >= 512 ? 2 : 1;
+            const int rows = ((n + nblk - 1) / nblk + 15) / 16 * 16;
+            for (int r0 = 0; r0 < n; r0 += rows) {
+                const int mr = std::min(rows, n - r0), kk = std::min(n, r0 + mr);
+                if (R.gemm(blas, ROC_OP_NONE, ROC_OP_NONE, mr, ncols, kk, &one, g.Linv + r0, n, h->gptile, n, &zero, vtile + r0, n) != 0)
+                    return fail(GPF_ERR_SOLVER, "rocblas_dgemm failed");
+            }
             v = vtile;
         } else if (R.trsm(blas, ROC_SIDE_LEFT, ROC_FILL_LOWER, ROC_OP_NONE, ROC_DIAG_NON_UNIT, n, ncols, &one, g.L, n, h->gptile, n) != 0) {
             return fail(GPF_ERR_SOLVER, "rocblas_dtrsm failed");
