@@ -13,6 +13,7 @@
 #include "aux_kernels.hip"
 #include "gp_kernels.hip"
 #include "elastic_kernels.hip"
+#include "small_kernel.hip"
 
 using namespace gpf;
 
@@ -725,6 +726,35 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     return GPF_OK;
 }
 
+// Problems that fit one workgroup's LDS advance whole batches of steps in one launch (small_kernel.hip).
+static bool small_grid_eligible(gpf_handle* h) {
+    static const bool off = getenv("GPF_SMALL_GRID") && atoi(getenv("GPF_SMALL_GRID")) == 0;
+    const long long nc = (long long)(h->L.Nx + 2) * (h->L.Ny + 2);
+    return !off && nc * SMALL_DOUBLES_PER_CELL * 8 <= 150 * 1024 && h->cfg.thinning == GPF_THINNING_NONE && !h->E.halo[0] && !h->E.halo[1] &&
+           !h->gp[0].set && !h->gp[1].set && !h->gp[2].set && !h->el.on;
+}
+
+static int enqueue_small_steps(gpf_handle* h, int nsteps, int honor_stop, long long log_base) {
+    const Layout& L = h->L;
+    SmallArgs a;
+    a.qa = h->q[0]; a.qb = h->q[1]; a.topo = h->topo; a.Ls = h->Ls; a.st = h->st;
+    a.log = h->log; a.log_base = log_base; a.log_cap = h->log_cap; a.L = L; a.E = h->E; a.nsteps = nsteps; a.honor_stop = honor_stop;
+    const size_t lds = (size_t)(L.Nx + 2) * (L.Ny + 2) * SMALL_DOUBLES_PER_CELL * 8;
+    EOS_DISPATCH(h->cfg.eos, {
+        if (h->Ls) {
+            HIP_TRY(hipFuncSetAttribute((const void*)k_small_steps<EOS_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_small_steps<EOS_, true>), dim3(1), dim3(512), lds, h->stream, a, h->P);
+        } else {
+            HIP_TRY(hipFuncSetAttribute((const void*)k_small_steps<EOS_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_small_steps<EOS_, false>), dim3(1), dim3(512), lds, h->stream, a, h->P);
+        }
+    });
+    HIP_TRY(hipGetLastError());
+    h->next_step += nsteps;
+    h->g1_ready = false;
+    return GPF_OK;
+}
+
 extern "C" int gpf_step(gpf_handle* h, int64_t n, int honor_stop, gpf_scalars_t* log, int64_t log_capacity,
                         int64_t* n_executed) {
     if (!h) return fail(GPF_ERR_INVALID, "null handle");
@@ -735,10 +765,12 @@ extern "C" int gpf_step(gpf_handle* h, int64_t n, int honor_stop, gpf_scalars_t*
     if (n < 0) return fail(GPF_ERR_INVALID, "gpf_step: n < 0");
     HIP_TRY(hipSetDevice(h->cfg.device));
     int64_t done = 0, logged = 0;
+    const bool small = small_grid_eligible(h);
     while (done < n) {
         const int64_t batch = std::min<int64_t>(n - done, h->log_cap);
         const long long base = h->host_step;
-        for (int64_t i = 0; i < batch; ++i) GPF_TRY(enqueue_step(h, honor_stop, base, nullptr));
+        if (small) GPF_TRY(enqueue_small_steps(h, (int)batch, honor_stop, base));
+        else for (int64_t i = 0; i < batch; ++i) GPF_TRY(enqueue_step(h, honor_stop, base, nullptr));
         StepState s;
         GPF_TRY(read_state(h, s));
         const long long ran = s.step - base;
