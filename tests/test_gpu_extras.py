@@ -117,3 +117,44 @@ properties: {{shear: 0.0794, bulk: 0., EOS: DH, rho0: 877.7007}}
         np.testing.assert_array_equal(f.variables['topography'][0][:, 0], prob.topo.full)
     cfg = yaml.safe_load(open(os.path.join(out, 'config.yml')))
     assert cfg['grid']['Nx'] == 50 and cfg['prop']['EOS'] == 'DH'
+
+
+def test_small_grid_kernel_equals_launch_per_kernel_path(hiplib, tmp_path):
+    """k_small_steps (one workgroup, many steps per launch) against the three-launch path on the same problem: two child
+    processes, because the switch (GPF_SMALL_GRID) is read once per process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = '''
+import sys, io, contextlib, numpy as np
+sys.path.insert(0, %r)
+from gapflow_amd import Problem
+text = """
+options: {silent: True}
+grid: {Nx: 33, Ny: 17, Lx: 0.01, Ly: 0.005, xE: ['D', 'N', 'N'], xW: ['D', 'N', 'N'], xE_D: 877.7007, xW_D: 876.,
+       yS: ['P', 'P', 'P'], yN: ['P', 'P', 'P']}
+geometry: {type: asperity, hmin: 2.e-6, hmax: 1.e-5, num: 1, U: 0.5, V: 0.1}
+numerics: {CFL: 0.4, adaptive: 1, MC_order: 0, tol: 1.e-14, max_it: 100000}
+properties: {EOS: DH, shear: 0.0794, bulk: 0., rho0: 877.7007, piezo: {name: Barus, aB: 2.e-8}}
+"""
+with contextlib.redirect_stdout(io.StringIO()):
+    p = Problem.from_string(text)
+    p._pre_run()
+    p._advance(37, honor_stop=False)
+    p._advance(40, honor_stop=False)
+np.savez(sys.argv[1], q=p.q, dt=p.dt, ekin=p.kinetic_energy, residual=p.residual, step=p.step, simtime=p.simtime)
+''' % root
+    out = {}
+    for mode in ('0', '1'):
+        fn = str(tmp_path / f'm{mode}.npz')
+        subprocess.run([sys.executable, '-c', code, fn], check=True, env=dict(os.environ, GPF_SMALL_GRID=mode), timeout=300)
+        out[mode] = np.load(fn)
+    a, b = out['0'], out['1']
+    assert int(a['step']) == int(b['step']) == 77
+    for c in range(3):
+        # two correct evaluation orders of a stiff problem (dp/drho ~ 1e8): rounding differences grow to ~1e-12 in 77 steps
+        assert np.abs(a['q'][c] - b['q'][c]).max() <= 1e-10 * np.abs(a['q'][c]).max(), c
+    np.testing.assert_allclose(b['dt'], a['dt'], rtol=1e-13)
+    np.testing.assert_allclose(b['simtime'], a['simtime'], rtol=1e-13)
+    np.testing.assert_allclose(b['ekin'], a['ekin'], rtol=1e-12)
