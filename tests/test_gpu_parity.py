@@ -154,9 +154,11 @@ properties: {{EOS: {eos}, shear: 0.1, bulk: 0., {props}}}
         assert np.isnan(prob.pressure.v_sound)
 
 
-def test_invalid_state_rolls_back(hiplib):
-    """NaN / negative density: the step is undone and the run stops (problem.py:565-610)."""
-    prob, fx, meta = make_problem('journal1d_readme')
+@pytest.mark.parametrize('name', ['journal1d_readme', 'slider2d_dn'])
+def test_invalid_state_rolls_back(hiplib, name):
+    """NaN / negative density: the step is undone and the run stops (problem.py:565-610).  The 1-D case runs through the
+    one-workgroup kernel for small problems, the 2-D one through the fused step."""
+    prob, fx, meta = make_problem(name)
     prob.update()
     good = prob.q.copy()
     prob._lib.gpf_set_dt(prob._h, 1.0)       # absurd time step -> negative densities
