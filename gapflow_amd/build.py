@@ -34,7 +34,7 @@ def build_library(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    extra = os.environ.get('GPF_EXTRA_FLAGS', '').split()        # diagnostics, e.g. -DGPF_EDGE_TIMING
+    extra = os.environ.get('GPF_EXTRA_FLAGS', '').split()        # diagnostics, e.g. -DGPF_STUB_CLOSURE
     cmd = [HIPCC] + FLAGS + extra + ['-Rpass-analysis=kernel-resource-usage', '-o', LIB] + SOURCES + LIBS
     res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
     with open(os.path.join(LIBDIR, 'resource_usage.txt'), 'w') as f:
