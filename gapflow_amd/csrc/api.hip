@@ -632,7 +632,7 @@ static int plan_step(gpf_handle* h) {
         const int want_chunks = std::max(1, resident / blocks_per_chunk);
         rows = (L.Nx + want_chunks - 1) / want_chunks;
     }
-    rows = std::max(std::getenv("GPF_ROWS_PER_CHUNK") ? 2 : 8, std::min(rows, L.Nx));
+    rows = std::max(4, std::min(rows, L.Nx));       // small grids: short chunks spread the rows over more CUs (256^2: 13.7 -> 10.8 us)
     if (rows > L.Nx) rows = L.Nx;
     h->rows_per_chunk = std::min(rows, std::max(L.Nx, 1));
     h->nchunks = (L.Nx + h->rows_per_chunk - 1) / h->rows_per_chunk;
