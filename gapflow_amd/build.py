@@ -14,8 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libgapflow_hip.so')
 SOURCES = ['api.hip']
-DEPS = ['api.hip', 'step_kernel.hip', 'aux_kernels.hip', 'gp_kernels.hip', 'closures.hpp', 'device_types.hpp',
-        os.path.join('..', '..', 'include', 'gapflow_hip.h')]
+DEPS = sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.hpp', '.inc'))) + [os.path.join('..', '..', 'include', 'gapflow_hip.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-value',
          '-ffp-contract=fast']

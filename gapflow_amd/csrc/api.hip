@@ -819,878 +819,13 @@ extern "C" int gpf_step_timed(gpf_handle* h, int64_t n, double* kernel_ms, doubl
     return rc;
 }
 
-// ---------------------------------------------------------------------------------------------
-// the unfused, reference-ordered step (problem.py:509-586 line by line)
-// ---------------------------------------------------------------------------------------------
-extern "C" int gpf_open_step(gpf_handle* h);
-extern "C" int gpf_stage_closures(gpf_handle* h);
-extern "C" int gpf_stage_advance(gpf_handle* h, int stage);
-extern "C" int gpf_close_step(gpf_handle* h, gpf_scalars_t* out);
-
-extern "C" int gpf_step_unfused(gpf_handle* h) {
-    if (!h) return fail(GPF_ERR_INVALID, "null handle");
-    if (!h->pre_run_done) return fail(GPF_ERR_STATE, "gpf_step_unfused: call gpf_pre_run first");
-    StepState s;
-    GPF_TRY(read_state(h, s));
-    if (s.invalid) return GPF_OK;
-    GPF_TRY(gpf_open_step(h));
-    for (int i = 0; i < 2; ++i) {
-        GPF_TRY(gpf_stage_closures(h));
-        GPF_TRY(gpf_stage_advance(h, i));
-    }
-    return gpf_close_step(h, nullptr);
-}
-
-// ---------------------------------------------------------------------------------------------
-// stateless operators (integrate.py)
-// ---------------------------------------------------------------------------------------------
-static Layout dense_layout(int nx, int ny) {
-    Layout L;
-    L.Nx = nx - 2; L.Ny = ny - 2; L.pitch = ny; L.off = 0; L.plane = (long long)nx * ny;
-    return L;
-}
-
-extern "C" int gpf_predictor_corrector(int nx, int ny, const double* q, const double* p, const double* tau,
-                                       int direction, double* flux_x, double* flux_y) {
-    if (!q || !p || !tau || !flux_x || !flux_y) return fail(GPF_ERR_INVALID, "gpf_predictor_corrector: null argument");
-    if (nx < 1 || ny < 1 || (direction != 1 && direction != -1))
-        return fail(GPF_ERR_INVALID, "gpf_predictor_corrector: nx, ny >= 1 and direction = +-1 required");
-    if (gpf_device_count() == 0) return fail(GPF_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
-    const Layout L = dense_layout(nx, ny);
-    const size_t n = (size_t)nx * ny;
-    double* d = nullptr;
-    HIP_TRY(hipMalloc(&d, 13 * n * sizeof(double)));
-    double *dq = d, *dp = d + 3 * n, *dt = d + 4 * n, *dfx = d + 7 * n, *dfy = d + 10 * n;
-    int rc = GPF_OK;
-    hipError_t e;
-    if ((e = hipMemcpy(dq, q, 3 * n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(dp, p, n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(dt, tau, 3 * n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) {
-        rc = fail(GPF_ERR_HIP, hipGetErrorString(e));
-    } else {
-        hipLaunchKernelGGL(k_fluxdiff, dim3(blocks_for((long long)n)), dim3(256), 0, 0, dq, dp, dt, direction, dfx, dfy, L);
-        if ((e = hipGetLastError()) != hipSuccess ||
-            (e = hipMemcpy(flux_x, dfx, 3 * n * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess ||
-            (e = hipMemcpy(flux_y, dfy, 3 * n * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess)
-            rc = fail(GPF_ERR_HIP, hipGetErrorString(e));
-    }
-    hipFree(d);
-    return rc;
-}
-
-extern "C" int gpf_source(int nx, int ny, const double* q, const double* hh, const double* stress, const double* lower,
-                          const double* upper, double* out) {
-    if (!q || !hh || !stress || !lower || !upper || !out) return fail(GPF_ERR_INVALID, "gpf_source: null argument");
-    if (nx < 1 || ny < 1) return fail(GPF_ERR_INVALID, "gpf_source: nx, ny >= 1 required");
-    if (gpf_device_count() == 0) return fail(GPF_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
-    const Layout L = dense_layout(nx, ny);
-    const size_t n = (size_t)nx * ny;
-    double* d = nullptr;
-    HIP_TRY(hipMalloc(&d, 24 * n * sizeof(double)));
-    double *dq = d, *dh = d + 3 * n, *ds = d + 6 * n, *dl = d + 9 * n, *du = d + 15 * n, *dout = d + 21 * n;
-    int rc = GPF_OK;
-    hipError_t e;
-    if ((e = hipMemcpy(dq, q, 3 * n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(dh, hh, 3 * n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(ds, stress, 3 * n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(dl, lower, 6 * n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(du, upper, 6 * n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) {
-        rc = fail(GPF_ERR_HIP, hipGetErrorString(e));
-    } else {
-        hipLaunchKernelGGL(k_source, dim3(blocks_for((long long)n)), dim3(256), 0, 0, dq, dh, ds, dl, du, dout, L);
-        if ((e = hipGetLastError()) != hipSuccess ||
-            (e = hipMemcpy(out, dout, 3 * n * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess)
-            rc = fail(GPF_ERR_HIP, hipGetErrorString(e));
-    }
-    hipFree(d);
-    return rc;
-}
-
-// models/viscous.py as functions of arrays: stress_bottom / stress_top / stress_avg in one call
-extern "C" int gpf_viscous_stress(int64_t n, const double* q, const double* hh, const double* dqx, const double* dqy,
-                                  const double* eta, const double* Ls, double U, double V, double zeta, int slip_both,
-                                  double* bottom, double* top, double* avg) {
-    if (!q || !hh || !eta || !Ls) return fail(GPF_ERR_INVALID, "gpf_viscous_stress: null argument");
-    if (!bottom && !top && !avg) return fail(GPF_ERR_INVALID, "gpf_viscous_stress: no output requested");
-    if (n < 1) return fail(GPF_ERR_INVALID, "gpf_viscous_stress: n >= 1 required");
-    if (gpf_device_count() == 0) return fail(GPF_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
-    const size_t N = (size_t)n;
-    double* d = nullptr;
-    HIP_TRY(hipMalloc(&d, 29 * N * sizeof(double)));
-    ViscousArgs a;
-    double* w = d;
-    auto put = [&](const double* host, size_t count, const double** dev) -> hipError_t {
-        *dev = nullptr;
-        if (!host) return hipSuccess;
-        *dev = w;
-        hipError_t e = hipMemcpy(w, host, count * sizeof(double), hipMemcpyHostToDevice);
-        w += count;
-        return e;
-    };
-    hipError_t e;
-    int rc = GPF_OK;
-    if ((e = put(q, 3 * N, &a.q)) != hipSuccess || (e = put(hh, 3 * N, &a.h)) != hipSuccess ||
-        (e = put(dqx, 3 * N, &a.dqx)) != hipSuccess || (e = put(dqy, 3 * N, &a.dqy)) != hipSuccess ||
-        (e = put(eta, N, &a.eta)) != hipSuccess || (e = put(Ls, N, &a.Ls)) != hipSuccess) {
-        rc = fail(GPF_ERR_HIP, hipGetErrorString(e));
-    } else {
-        a.U = U; a.V = V; a.zeta = zeta; a.slip_both = slip_both ? 1 : 0; a.n = n;
-        a.out[0] = bottom ? w : nullptr; if (bottom) w += 6 * N;
-        a.out[1] = top ? w : nullptr; if (top) w += 6 * N;
-        a.out[2] = avg ? w : nullptr;
-        hipLaunchKernelGGL(k_viscous, dim3(blocks_for((long long)n)), dim3(256), 0, 0, a);
-        if ((e = hipGetLastError()) != hipSuccess ||
-            (bottom && (e = hipMemcpy(bottom, a.out[0], 6 * N * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) ||
-            (top && (e = hipMemcpy(top, a.out[1], 6 * N * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) ||
-            (avg && (e = hipMemcpy(avg, a.out[2], 3 * N * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess))
-            rc = fail(GPF_ERR_HIP, hipGetErrorString(e));
-    }
-    hipFree(d);
-    return rc;
-}
-
-// models/pressure.py eos_pressure and models/sound.py eos_sound_velocity as functions of an array
-extern "C" int gpf_eos(int eos, const double* eos_par, int64_t n, const double* rho, double* pressure, double* sound) {
-    if (!eos_par || !rho || (!pressure && !sound)) return fail(GPF_ERR_INVALID, "gpf_eos: null argument");
-    if (eos < 0 || eos > GPF_EOS_BAYADA) return fail(GPF_ERR_INVALID, "gpf_eos: unknown equation of state");
-    if (n < 1) return fail(GPF_ERR_INVALID, "gpf_eos: n >= 1 required");
-    if (gpf_device_count() == 0) return fail(GPF_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
-    gpf_config c;
-    std::memset(&c, 0, sizeof(c));
-    c.eos = eos; c.dx = c.dy = 1.0;
-    for (int i = 0; i < 8; ++i) c.eos_par[i] = eos_par[i];
-    Phys P;
-    make_phys(c, P);
-    const size_t N = (size_t)n;
-    double* d = nullptr;
-    HIP_TRY(hipMalloc(&d, 3 * N * sizeof(double)));
-    hipError_t e;
-    int rc = GPF_OK;
-    if ((e = hipMemcpy(d, rho, N * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) {
-        rc = fail(GPF_ERR_HIP, hipGetErrorString(e));
-    } else {
-        double* dp = pressure ? d + N : nullptr;
-        double* dc = sound ? d + 2 * N : nullptr;
-        EOS_DISPATCH(eos, { hipLaunchKernelGGL((k_eos<EOS_>), dim3(blocks_for((long long)n)), dim3(256), 0, 0, d, (long long)n, P, dp, dc); });
-        if ((e = hipGetLastError()) != hipSuccess ||
-            (pressure && (e = hipMemcpy(pressure, dp, N * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) ||
-            (sound && (e = hipMemcpy(sound, dc, N * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess))
-            rc = fail(GPF_ERR_HIP, hipGetErrorString(e));
-    }
-    hipFree(d);
-    return rc;
-}
-
-// models/viscosity.py as functions of arrays
-extern "C" int gpf_viscosity(int kind, int law, const double* par, double mu0, int64_t n, const double* a0, const double* a1,
-                             const double* a2, double u1, double u2, double* out) {
-    if (!a0 || !out || (kind == 2 && (!a1 || !a2)) || (kind != 2 && !par)) return fail(GPF_ERR_INVALID, "gpf_viscosity: null argument");
-    if (kind < 0 || kind > 2 || n < 1) return fail(GPF_ERR_INVALID, "gpf_viscosity: kind in 0..2 and n >= 1 required");
-    if ((kind == 0 && (law < 0 || law > GPF_PIEZO_MCADAMS)) || (kind == 1 && (law < 0 || law > GPF_THINNING_CARREAU)))
-        return fail(GPF_ERR_INVALID, "gpf_viscosity: unknown law");
-    if (gpf_device_count() == 0) return fail(GPF_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
-    gpf_config c;
-    std::memset(&c, 0, sizeof(c));
-    c.eos = GPF_EOS_DH; c.dx = c.dy = 1.0; c.eta = mu0;
-    c.eos_par[0] = 1.0; c.eos_par[2] = 1.0; c.eos_par[3] = 2.0;
-    if (kind == 0) { c.piezo = law; for (int i = 0; i < 4; ++i) c.piezo_par[i] = par[i]; }
-    if (kind == 1) { c.thinning = law; for (int i = 0; i < 4; ++i) c.thinning_par[i] = par[i]; }
-    Phys P;
-    make_phys(c, P);
-    const size_t N = (size_t)n;
-    double* d = nullptr;
-    HIP_TRY(hipMalloc(&d, 4 * N * sizeof(double)));
-    hipError_t e = hipMemcpy(d, a0, N * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess && kind == 2) e = hipMemcpy(d + N, a1, N * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess && kind == 2) e = hipMemcpy(d + 2 * N, a2, N * sizeof(double), hipMemcpyHostToDevice);
-    int rc = GPF_OK;
-    if (e != hipSuccess) {
-        rc = fail(GPF_ERR_HIP, hipGetErrorString(e));
-    } else {
-        hipLaunchKernelGGL(k_viscosity, dim3(blocks_for((long long)n)), dim3(256), 0, 0, kind, d, d + N, d + 2 * N, (long long)n,
-                           mu0, u1, u2, P, d + 3 * N);
-        if ((e = hipGetLastError()) != hipSuccess || (e = hipMemcpy(out, d + 3 * N, N * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess)
-            rc = fail(GPF_ERR_HIP, hipGetErrorString(e));
-    }
-    hipFree(d);
-    return rc;
-}
-
-// ---------------------------------------------------------------------------------------------
-// slab decomposition
-// ---------------------------------------------------------------------------------------------
-static size_t halo_len(gpf_handle* h) { return (size_t)6 * h->L.pitch + 8; }
-
-static int ensure_halo(gpf_handle* h) {
-    if (h->halo) return GPF_OK;
-    HIP_TRY(hipMalloc(&h->halo, halo_len(h) * sizeof(double)));
-    HIP_TRY(hipMemsetAsync(h->halo, 0, halo_len(h) * sizeof(double), h->stream));
-    return GPF_OK;
-}
-
-extern "C" int gpf_slab_message(gpf_handle* h, void** message, size_t* count) {
-    if (!h || !message || !count) return fail(GPF_ERR_INVALID, "gpf_slab_message: null argument");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    GPF_TRY(ensure_halo(h));
-    *message = h->halo;
-    *count = halo_len(h);
-    return GPF_OK;
-}
-
-static HaloArgs halo_args(gpf_handle* h, int honor_stop, const double* gathered, int rank_lo, int rank_hi) {
-    HaloArgs a;
-    a.qa = h->q[0]; a.qb = h->q[1];
-    a.msg = h->halo; a.gathered = gathered; a.rank_lo = rank_lo; a.rank_hi = rank_hi;
-    a.st = h->st; a.L = h->L; a.E = h->E; a.honor_stop = honor_stop;
-    a.work_parity = -1;
-    return a;
-}
-
-extern "C" int gpf_step_local(gpf_handle* h, int honor_stop) {
-    if (!h) return fail(GPF_ERR_INVALID, "gpf_step_local: null handle");
-    if (!h->pre_run_done) return fail(GPF_ERR_STATE, "gpf_step_local: call gpf_pre_run first");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    GPF_TRY(ensure_halo(h));
-    double* rec = h->halo + (size_t)6 * h->L.pitch;
-    GPF_TRY(enqueue_step(h, honor_stop, h->host_step, rec));      // leaves rows and record in the message
-    return GPF_OK;
-}
-
-extern "C" int gpf_step_commit(gpf_handle* h, int honor_stop, const void* gathered, int nranks, int rank_lo, int rank_hi) {
-    if (!h || !gathered || nranks < 1) return fail(GPF_ERR_INVALID, "gpf_step_commit: bad argument");
-    if (rank_lo >= nranks || rank_hi >= nranks) return fail(GPF_ERR_INVALID, "gpf_step_commit: neighbour rank out of range");
-    if (!h->halo) return fail(GPF_ERR_STATE, "gpf_step_commit without gpf_step_local");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    // one launch: scatter the neighbours' rows, reduce the records in rank order, commit, and prepare the next step's
-    // stage-1 ghost data (so the next gpf_step_local starts with the stencil)
-    const Layout& L = h->L;
-    GhostArgs g;
-    GPF_TRY(ghost_args(h, honor_stop, g));
-    WaitArgs w;
-    w.qa = h->q[0]; w.qb = h->q[1]; w.st = h->st; w.log = h->log; w.log_base = h->host_step; w.log_cap = h->log_cap;
-    w.L = L; w.E = h->E; w.honor_stop = honor_stop; w.arrive = h->arrive + 1; w.p2p = p2p_args(h, false);
-    w.gathered = (const double*)gathered; w.msg_len = (long long)halo_len(h); w.nranks = nranks; w.rank_lo = rank_lo; w.rank_hi = rank_hi;
-    const dim3 ggrid(std::min((L.Nx + L.Ny + 63) / 64, 512));
-    EOS_DISPATCH(h->cfg.eos, {
-        if (h->Ls) hipLaunchKernelGGL((k_begin_slab<EOS_, true, false>), ggrid, dim3(256), 0, h->stream, g, w, h->P);
-        else hipLaunchKernelGGL((k_begin_slab<EOS_, false, false>), ggrid, dim3(256), 0, h->stream, g, w, h->P);
-    });
-    HIP_TRY(hipGetLastError());
-    h->g1_ready = true;
-    return GPF_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// elastic deformation of the gap (topography.py:257-280, 327-437)
-// ---------------------------------------------------------------------------------------------
-extern "C" int gpf_elastic_setup(gpf_handle* h, int px, int py, const double* greens_ri, size_t count, double alpha,
-                                 double force_scale, int relative) {
-    if (!h || !greens_ri) return fail(GPF_ERR_INVALID, "gpf_elastic_setup: null argument");
-    const Layout& L = h->L;
-    if (px < L.Nx + 2 || py < L.Ny + 2) return fail(GPF_ERR_INVALID, "gpf_elastic_setup: the transform grid must hold the field incl. ghost cells");
-    const size_t nspec = (size_t)px * (py / 2 + 1);
-    if (count != 2 * nspec) return fail(GPF_ERR_INVALID, "gpf_elastic_setup: count must be 2 * px * (py/2 + 1) (real, imaginary)");
-    if (!h->has_topo) return fail(GPF_ERR_STATE, "gpf_elastic_setup: upload the undeformed topography first");
-    if (h->E.halo[0] || h->E.halo[1]) return fail(GPF_ERR_STATE, "gpf_elastic_setup: not available for slabs (the half-space couples the whole domain)");
-    FftLib& F = fftlib();
-    if (!F.ok) return fail(GPF_ERR_SOLVER, F.err);
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    auto& e = h->el;
-    if (e.on) return fail(GPF_ERR_STATE, "gpf_elastic_setup: already set up");
-    HIP_TRY(hipMalloc((void**)&e.greens, nspec * sizeof(double2)));
-    HIP_TRY(hipMalloc((void**)&e.spec, nspec * sizeof(double2)));
-    HIP_TRY(hipMalloc((void**)&e.dense, (size_t)px * py * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&e.u_prev, (size_t)3 * L.plane * sizeof(double)));
-    e.h0 = e.u_prev + L.plane; e.deformation = e.u_prev + 2 * L.plane;
-    HIP_TRY(hipMemset(e.u_prev, 0, (size_t)3 * L.plane * sizeof(double)));
-    HIP_TRY(hipMemcpy(e.greens, greens_ri, nspec * sizeof(double2), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e.h0, h->topo, (size_t)L.plane * sizeof(double), hipMemcpyDeviceToDevice));
-    if (F.plan2d(&e.plan_f, px, py, HIPFFT_D2Z_) != 0 || F.plan2d(&e.plan_b, px, py, HIPFFT_Z2D_) != 0)
-        return fail(GPF_ERR_SOLVER, "hipfftPlan2d failed");
-    e.px = px; e.py = py; e.alpha = alpha; e.relative = relative ? 1 : 0;
-    e.scale = force_scale / ((double)px * (double)py);      // hipFFT's inverse is unnormalised
-    e.on = true;
-    h->topo_mode = 0;                                       // the gap now changes every step: read the planes
-    return GPF_OK;
-}
-
-// Topography.update + update_gradients with the pressure of the last closure evaluation (problem.py:566 uses the
-// stored field, i.e. stage 2's): h, dh/dx, dh/dy of the handle change in place.
-extern "C" int gpf_elastic_update(gpf_handle* h) {
-    if (!h) return fail(GPF_ERR_INVALID, "gpf_elastic_update: null handle");
-    auto& e = h->el;
-    if (!e.on) return fail(GPF_ERR_STATE, "gpf_elastic_update: call gpf_elastic_setup first");
-    if (!h->fields) return fail(GPF_ERR_STATE, "gpf_elastic_update: no pressure field yet (gpf_stage_closures / gpf_update_closures)");
-    FftLib& F = fftlib();
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    const Layout& L = h->L;
-    const long long nd = (long long)e.px * e.py, ns = (long long)e.px * (e.py / 2 + 1), nc = (long long)(L.Nx + 2) * (L.Ny + 2);
-    F.set_stream(e.plan_f, h->stream); F.set_stream(e.plan_b, h->stream);
-    hipLaunchKernelGGL(k_el_pack, dim3(blocks_for(nd)), dim3(256), 0, h->stream, h->fields, L, e.px, e.py, e.relative, e.dense);
-    if (F.d2z(e.plan_f, e.dense, e.spec) != 0) return fail(GPF_ERR_SOLVER, "hipfftExecD2Z failed");
-    hipLaunchKernelGGL(k_el_multiply, dim3(blocks_for(ns)), dim3(256), 0, h->stream, e.spec, e.greens, ns);
-    if (F.z2d(e.plan_b, e.spec, e.dense) != 0) return fail(GPF_ERR_SOLVER, "hipfftExecZ2D failed");
-    hipLaunchKernelGGL(k_el_relax, dim3(blocks_for(nc)), dim3(256), 0, h->stream, e.dense, e.py, e.scale, e.alpha, L, e.u_prev);
-    hipLaunchKernelGGL(k_el_apply, dim3(blocks_for(nc)), dim3(256), 0, h->stream, e.u_prev, e.h0, e.relative, L, e.deformation, h->topo);
-    hipLaunchKernelGGL(k_el_gradient, dim3(blocks_for(nc)), dim3(256), 0, h->stream, h->topo, L, 1.0 / h->cfg.dx, 1.0 / h->cfg.dy,
-                       h->topo + L.plane, h->topo + 2 * L.plane);
-    HIP_TRY(hipGetLastError());
-    h->g1_ready = false;
-    return GPF_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// peer-to-peer slab transport
-// ---------------------------------------------------------------------------------------------
-extern "C" int gpf_p2p_export(gpf_handle* h, void* ipc_handle, size_t handle_bytes) {
-    if (!h || !ipc_handle) return fail(GPF_ERR_INVALID, "gpf_p2p_export: null argument");
-    if (handle_bytes != sizeof(hipIpcMemHandle_t)) return fail(GPF_ERR_INVALID, "gpf_p2p_export: the handle buffer must hold 64 bytes");
-    if (h->p2p.on) return fail(GPF_ERR_STATE, "gpf_p2p_export: already connected");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    const size_t bytes = p2p_mailbox_bytes(h->L.pitch);
-    if (!h->p2p.mine) {
-        // fine-grained: peers' stores become visible to a kernel that is already running here
-        HIP_TRY(hipExtMallocWithFlags((void**)&h->p2p.mine, bytes, hipDeviceMallocFinegrained));
-    }
-    HIP_TRY(hipMemset(h->p2p.mine, 0, bytes));
-    HIP_TRY(hipDeviceSynchronize());
-    hipIpcMemHandle_t hm;
-    HIP_TRY(hipIpcGetMemHandle(&hm, h->p2p.mine));
-    std::memcpy(ipc_handle, &hm, sizeof(hm));
-    return GPF_OK;
-}
-
-extern "C" int gpf_p2p_connect(gpf_handle* h, int rank, int nranks, const void* ipc_handles, int rank_lo, int rank_hi) {
-    if (!h || !ipc_handles) return fail(GPF_ERR_INVALID, "gpf_p2p_connect: null argument");
-    if (nranks < 1 || nranks > P2P_MAX_RANKS) return fail(GPF_ERR_INVALID, "gpf_p2p_connect: 1 <= nranks <= 16");
-    if (rank < 0 || rank >= nranks || rank_lo >= nranks || rank_hi >= nranks) return fail(GPF_ERR_INVALID, "gpf_p2p_connect: rank out of range");
-    if (!h->p2p.mine) return fail(GPF_ERR_STATE, "gpf_p2p_connect: call gpf_p2p_export first");
-    if (h->p2p.on) return fail(GPF_ERR_STATE, "gpf_p2p_connect: already connected");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    const hipIpcMemHandle_t* hs = (const hipIpcMemHandle_t*)ipc_handles;
-    for (int r = 0; r < nranks; ++r) {
-        if (r == rank) { h->p2p.box[r] = h->p2p.mine; continue; }
-        void* p = nullptr;
-        hipError_t e = hipIpcOpenMemHandle(&p, hs[r], hipIpcMemLazyEnablePeerAccess);
-        if (e != hipSuccess) {
-            for (int k = 0; k < r; ++k)
-                if (k != rank && h->p2p.box[k]) { hipIpcCloseMemHandle(h->p2p.box[k]); h->p2p.box[k] = nullptr; }
-            return fail(GPF_ERR_HIP, std::string("gpf_p2p_connect: hipIpcOpenMemHandle(rank ") + std::to_string(r) + "): " + hipGetErrorString(e));
-        }
-        h->p2p.box[r] = (char*)p;
-    }
-    if (!h->p2p.seq) HIP_TRY(hipMalloc((void**)&h->p2p.seq, sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(h->p2p.seq, 0, sizeof(unsigned long long)));
-    HIP_TRY(hipDeviceSynchronize());
-    h->p2p.nranks = nranks; h->p2p.rank = rank; h->p2p.rank_lo = rank_lo; h->p2p.rank_hi = rank_hi;
-    h->p2p.on = true;
-    return GPF_OK;
-}
-
-// n whole steps, exchanges included, enqueued without touching the host in between
-extern "C" int gpf_step_p2p(gpf_handle* h, int64_t n, int honor_stop) {
-    if (!h) return fail(GPF_ERR_INVALID, "gpf_step_p2p: null handle");
-    if (!h->pre_run_done) return fail(GPF_ERR_STATE, "gpf_step_p2p: call gpf_pre_run first");
-    if (!h->p2p.on) return fail(GPF_ERR_STATE, "gpf_step_p2p: call gpf_p2p_export / gpf_p2p_connect first");
-    if (n < 0) return fail(GPF_ERR_INVALID, "gpf_step_p2p: n < 0");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    GPF_TRY(ensure_halo(h));
-    double* rec = h->halo + (size_t)6 * h->L.pitch;
-    for (int64_t i = 0; i < n; ++i) GPF_TRY(enqueue_step(h, honor_stop, h->host_step, rec, nullptr, nullptr, true));
-    return GPF_OK;
-}
-
-extern "C" int gpf_state(gpf_handle* h, gpf_scalars_t* out) {
-    if (!h || !out) return fail(GPF_ERR_INVALID, "gpf_state: null argument");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    StepState s;
-    GPF_TRY(read_state(h, s));
-    fill_scalars(s, nullptr, 0.0, out);
-    h->host_step = s.step; h->next_step = s.step;
-    return GPF_OK;
-}
-
-extern "C" int gpf_set_seam_topo(gpf_handle* h, int side, const double* host, size_t count) {
-    if (!h || !host || side < 0 || side > 1) return fail(GPF_ERR_INVALID, "gpf_set_seam_topo: bad argument");
-    const Layout& L = h->L;
-    if (count != (size_t)8 * (L.Ny + 2)) return fail(GPF_ERR_INVALID, "gpf_set_seam_topo: count must be 2*4*(Ny+2)");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    if (!h->seam) {
-        HIP_TRY(hipMalloc(&h->seam, (size_t)16 * L.pitch * sizeof(double)));
-        HIP_TRY(hipMemset(h->seam, 0, (size_t)16 * L.pitch * sizeof(double)));
-    }
-    std::vector<double> tmp((size_t)8 * L.pitch, 0.0);
-    for (int r = 0; r < 8; ++r)
-        for (int iy = 0; iy < L.Ny + 2; ++iy) tmp[(size_t)r * L.pitch + L.off + iy] = host[(size_t)r * (L.Ny + 2) + iy];
-    HIP_TRY(hipMemcpy(h->seam + (size_t)side * 8 * L.pitch, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
-    h->has_seam[side] = true;
-    return GPF_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// GP surrogate closure (gp_kernels.hip)
-// ---------------------------------------------------------------------------------------------
-static int gp_blas(gpf_handle* h, void** out) {
-    RocLibs& R = roclibs();
-    if (!R.ok) return fail(GPF_ERR_SOLVER, R.err);
-    if (!h->blas) {
-        if (R.create(&h->blas) != 0) return fail(GPF_ERR_SOLVER, "rocblas_create_handle failed");
-    }
-    if (R.set_stream(h->blas, h->stream) != 0) return fail(GPF_ERR_SOLVER, "rocblas_set_stream failed");
-    *out = h->blas;
-    return GPF_OK;
-}
-
-// Builds K from kernel-coordinate inputs Z (device, [n][d]), factorises it in place (column-major lower),
-// solves for alpha (device, column-major [n][m], holds Y on entry).  *info_host != 0: not positive definite.
-static int gp_factorize(void* blas, hipStream_t stream, const double* Z, int n, int d, int m, double amp, double sigma,
-                        double* K, double* alpha, int* info_host) {
-    RocLibs& R = roclibs();
-    DBG("gp_factorize: kernel matrix n=%d d=%d m=%d", n, d, m);
-    hipLaunchKernelGGL(k_gp_matrix, dim3((n + 127) / 128, n), dim3(128), 0, stream, Z, n, d, amp, sigma * sigma, K);
-    HIP_TRY(hipGetLastError());
-    int* info = nullptr;
-    HIP_TRY(hipMalloc(&info, sizeof(int)));
-    int rc = 0;
-    if (R.potrf) {      // GPF_USE_ROCSOLVER=1
-        DBG("gp_factorize: rocsolver dpotrf");
-        rc = R.potrf(blas, ROC_FILL_LOWER, n, K, n, info);
-        if (rc == 0) rc = R.potrs(blas, ROC_FILL_LOWER, n, m, K, n, alpha, n);
-    } else if (R.gemm && n > 96 && !getenv("GPF_GP_UNBLOCKED_POTRF")) {
-        // right-looking blocked Cholesky: 64 x 64 diagonal blocks in one workgroup, the panel solve and the trailing update
-        // on rocBLAS (dtrsm, dgemm on the matrix cores): 12 ms -> ~1 ms at n = 512
-        const int NB = 64;
-        const double one = 1.0, minus = -1.0;
-        for (int j0 = 0; j0 < n && rc == 0; j0 += NB) {
-            const int jb = std::min(NB, n - j0), rest = n - j0 - jb;
-            double* A11 = K + j0 + (long long)j0 * n;
-            hipLaunchKernelGGL(k_gp_potrf, dim3(1), dim3(1024), 0, stream, A11, jb, n, j0, info);
-            if (rest > 0) {
-                double* A21 = A11 + jb;
-                double* A22 = A21 + (long long)jb * n;
-                rc = R.trsm(blas, ROC_SIDE_RIGHT, ROC_FILL_LOWER, ROC_OP_TRANS, ROC_DIAG_NON_UNIT, rest, jb, &one, A11, n, A21, n);
-                if (rc == 0) rc = R.gemm(blas, ROC_OP_NONE, ROC_OP_TRANS, rest, rest, jb, &minus, A21, n, A21, n, &one, A22, n);
-            }
-        }
-        hipLaunchKernelGGL(k_gp_potrs, dim3(1), dim3(1024), 0, stream, K, n, m, alpha);
-    } else {
-        hipLaunchKernelGGL(k_gp_potrf, dim3(1), dim3(1024), 0, stream, K, n, n, 0, info);
-        hipLaunchKernelGGL(k_gp_potrs, dim3(1), dim3(1024), 0, stream, K, n, m, alpha);
-    }
-    hipError_t e = hipMemcpyAsync(info_host, info, sizeof(int), hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    hipFree(info);
-    if (rc != 0) return fail(GPF_ERR_SOLVER, "rocBLAS / rocSOLVER returned status " + std::to_string(rc) + " in the Cholesky factorisation");
-    if (e != hipSuccess) return fail(GPF_ERR_HIP, hipGetErrorString(e));
-    hipLaunchKernelGGL(k_gp_clean_lower, dim3((n + 127) / 128, n), dim3(128), 0, stream, K, n);
-    HIP_TRY(hipGetLastError());
-    return GPF_OK;
-}
-
-extern "C" int gpf_gp_fit(int device, int n, int d, int m, const double* Xn, const double* Yn, double amp,
-                          const double* inv_scale, double sigma, double* L_out, double* alpha_out, double* logdet) {
-    if (!Xn || !Yn || !inv_scale) return fail(GPF_ERR_INVALID, "gpf_gp_fit: null argument");
-    if (n < 1 || d < 1 || d > GP_MAX_D || m < 1 || m > 2) return fail(GPF_ERR_INVALID, "gpf_gp_fit: need n>=1, 1<=d<=4, 1<=m<=2");
-    if (gpf_device_count() == 0) return fail(GPF_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
-    HIP_TRY(hipSetDevice(device));
-    DBG("gpf_gp_fit: dlopen rocBLAS/rocSOLVER");
-    RocLibs& R = roclibs();
-    if (!R.ok) return fail(GPF_ERR_SOLVER, R.err);
-    DBG("gpf_gp_fit: libraries ready");
-    std::vector<double> Z((size_t)n * d), Ycm((size_t)n * m);
-    for (int i = 0; i < n; ++i) {
-        for (int k = 0; k < d; ++k) Z[(size_t)i * d + k] = Xn[(size_t)i * d + k] * inv_scale[k];
-        for (int o = 0; o < m; ++o) Ycm[(size_t)o * n + i] = Yn[(size_t)i * m + o];
-    }
-    double *dZ = nullptr, *dK = nullptr, *dA = nullptr, *dld = nullptr;
-    void* blas = nullptr;
-    int rc = GPF_OK, info = 0;
-    auto done = [&](int code) {
-        if (dZ) hipFree(dZ);
-        if (dK) hipFree(dK);
-        if (dA) hipFree(dA);
-        if (dld) hipFree(dld);
-        if (blas) R.destroy(blas);
-        return code;
-    };
-    if (hipMalloc(&dZ, Z.size() * 8) != hipSuccess || hipMalloc(&dK, (size_t)n * n * 8) != hipSuccess ||
-        hipMalloc(&dA, Ycm.size() * 8) != hipSuccess || hipMalloc(&dld, 8) != hipSuccess)
-        return done(fail(GPF_ERR_HIP, "gpf_gp_fit: hipMalloc failed"));
-    hipMemcpy(dZ, Z.data(), Z.size() * 8, hipMemcpyHostToDevice);
-    hipMemcpy(dA, Ycm.data(), Ycm.size() * 8, hipMemcpyHostToDevice);
-    DBG("gpf_gp_fit: rocblas_create_handle");
-    if (R.create(&blas) != 0) return done(fail(GPF_ERR_SOLVER, "rocblas_create_handle failed"));
-    DBG("gpf_gp_fit: handle created");
-    rc = gp_factorize(blas, nullptr, dZ, n, d, m, amp, sigma, dK, dA, &info);
-    if (rc != GPF_OK) return done(rc);
-    if (info != 0) return done(fail(GPF_ERR_SOLVER, "gpf_gp_fit: kernel matrix not positive definite (dpotrf info = " + std::to_string(info) + ")"));
-    hipLaunchKernelGGL(k_gp_logdet, dim3(1), dim3(1), 0, 0, dK, n, dld);
-    if (logdet) hipMemcpy(logdet, dld, 8, hipMemcpyDeviceToHost);
-    if (alpha_out) {
-        hipMemcpy(Ycm.data(), dA, Ycm.size() * 8, hipMemcpyDeviceToHost);
-        for (int i = 0; i < n; ++i)
-            for (int o = 0; o < m; ++o) alpha_out[(size_t)i * m + o] = Ycm[(size_t)o * n + i];
-    }
-    if (L_out) {
-        std::vector<double> Lc((size_t)n * n);
-        hipMemcpy(Lc.data(), dK, Lc.size() * 8, hipMemcpyDeviceToHost);
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j < n; ++j) L_out[(size_t)i * n + j] = Lc[(size_t)j * n + i];      // row-major out
-    }
-    hipError_t e = hipDeviceSynchronize();
-    if (e != hipSuccess) return done(fail(GPF_ERR_HIP, hipGetErrorString(e)));
-    return done(GPF_OK);
-}
-
-extern "C" int gpf_gp_clear_model(gpf_handle* h, int which) {
-    if (!h || which < 0 || which > 2) return fail(GPF_ERR_INVALID, "gpf_gp_clear_model: bad argument");
-    auto& g = h->gp[which];
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (g.Z) hipFree(g.Z);
-    if (g.alpha) hipFree(g.alpha);
-    if (g.L) hipFree(g.L);
-    if (g.Linv) hipFree(g.Linv);
-    g.Z = g.alpha = g.L = g.Linv = nullptr;
-    g.cap = 0;
-    g.set = false;
-    return GPF_OK;
-}
-
-extern "C" int gpf_gp_set_model(gpf_handle* h, int which, int n, int d, int m, const int32_t* dims, const double* x_scale,
-                                const double* Xn, const double* Yn, double amp, const double* inv_scale, double sigma,
-                                double yscale) {
-    if (!h || !dims || !x_scale || !Xn || !Yn || !inv_scale) return fail(GPF_ERR_INVALID, "gpf_gp_set_model: null argument");
-    if (which < 0 || which > 2) return fail(GPF_ERR_INVALID, "gpf_gp_set_model: which must be 0 (press), 1 (shear xz), 2 (shear yz)");
-    if (n < 1 || d < 1 || d > GP_MAX_D) return fail(GPF_ERR_INVALID, "gpf_gp_set_model: need n >= 1 and 1 <= d <= 4");
-    if (m != (which == 0 ? 1 : 2)) return fail(GPF_ERR_INVALID, "gpf_gp_set_model: pressure has 1 output, wall shear 2 (lower, upper)");
-    for (int k = 0; k < d; ++k)
-        if (dims[k] < 0 || dims[k] > 6) return fail(GPF_ERR_INVALID, "gpf_gp_set_model: feature index out of range 0..6");
-    auto& g = h->gp[which];
-    // active learning refits after every added point: keep the buffers while they are large enough
-    if (n > g.cap) {
-        GPF_TRY(gpf_gp_clear_model(h, which));
-        const size_t cap = (size_t)((n + 127) / 128) * 128;
-        HIP_TRY(hipMalloc(&g.Z, cap * GP_MAX_D * 8));
-        HIP_TRY(hipMalloc(&g.alpha, cap * 2 * 8));
-        HIP_TRY(hipMalloc(&g.L, cap * cap * 8));
-        HIP_TRY(hipMalloc(&g.Linv, cap * cap * 8));
-        g.cap = (int)cap;
-    } else {
-        HIP_TRY(hipStreamSynchronize(h->stream));      // nothing may still read the old model
-    }
-    g.set = false;
-    void* blas = nullptr;
-    GPF_TRY(gp_blas(h, &blas));
-    std::vector<double> Z((size_t)n * d), Ycm((size_t)n * m);
-    for (int i = 0; i < n; ++i) {
-        for (int k = 0; k < d; ++k) Z[(size_t)i * d + k] = Xn[(size_t)i * d + k] * inv_scale[k];
-        for (int o = 0; o < m; ++o) Ycm[(size_t)o * n + i] = Yn[(size_t)i * m + o];
-    }
-    HIP_TRY(hipMemcpyAsync(g.Z, Z.data(), Z.size() * 8, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(g.alpha, Ycm.data(), Ycm.size() * 8, hipMemcpyHostToDevice, h->stream));
-    int info = 0;
-    GPF_TRY(gp_factorize(blas, h->stream, g.Z, n, d, m, amp, sigma, g.L, g.alpha, &info));
-    if (info != 0) {
-        gpf_gp_clear_model(h, which);
-        return fail(GPF_ERR_SOLVER, "gpf_gp_set_model: kernel matrix not positive definite (dpotrf info = " + std::to_string(info) + ")");
-    }
-    GpModelDev& D = g.dev;
-    D.n = n; D.d = d; D.m = m; D.amp = amp; D.yscale = yscale;
-    for (int k = 0; k < GP_MAX_D; ++k) { D.dims[k] = k < d ? dims[k] : 0; D.fscale[k] = k < d ? inv_scale[k] / x_scale[k] : 0.0; }
-    D.Z = g.Z; D.alpha = g.alpha; D.L = g.L;
-    g.xscale0 = x_scale[0];
-    // L^-1 once per fit (n^3/3 flops): the predictive variance then is a dense product V = L^-1 Ks on the matrix cores
-    // (rocBLAS dgemm) instead of a triangular solve per tile, 3-4x faster for a few hundred training points.
-    // cond(L) = sqrt(cond(K)), so the explicit inverse costs no accuracy that the factorisation had.
-    if (roclibs().gemm && !(getenv("GPF_GP_VARIANCE") && std::string(getenv("GPF_GP_VARIANCE")) == "trsm")) {
-        RocLibs& R = roclibs();
-        const double one = 1.0;
-        hipLaunchKernelGGL(k_gp_identity, dim3((n + 127) / 128, n), dim3(128), 0, h->stream, g.Linv, n);
-        hipLaunchKernelGGL(k_gp_clean_lower, dim3((n + 127) / 128, n), dim3(128), 0, h->stream, g.L, n);
-        HIP_TRY(hipGetLastError());
-        if (R.trsm(blas, ROC_SIDE_LEFT, ROC_FILL_LOWER, ROC_OP_NONE, ROC_DIAG_NON_UNIT, n, n, &one, g.L, n, g.Linv, n) != 0)
-            return fail(GPF_ERR_SOLVER, "rocblas_dtrsm (inverse of the Cholesky factor) failed");
-        hipLaunchKernelGGL(k_gp_clean_lower, dim3((n + 127) / 128, n), dim3(128), 0, h->stream, g.Linv, n);
-        HIP_TRY(hipGetLastError());
-        g.has_linv = true;
-    } else {
-        g.has_linv = false;
-    }
-    g.set = true;
-    if (!h->gpvar) {
-        HIP_TRY(hipMalloc(&h->gpvar, (size_t)3 * h->L.plane * 8));
-        HIP_TRY(hipMemsetAsync(h->gpvar, 0, (size_t)3 * h->L.plane * 8, h->stream));
-    }
-    return GPF_OK;
-}
-
-static int gp_scratch(gpf_handle* h, int nblocks) {
-    if (h->gpscratch_n >= nblocks) return GPF_OK;
-    if (h->gpscratch) HIP_TRY(hipFree(h->gpscratch));
-    h->gpscratch = nullptr;
-    HIP_TRY(hipMalloc(&h->gpscratch, ((size_t)nblocks + 8) * 8));
-    h->gpscratch_n = nblocks;
-    return GPF_OK;
-}
-
-static GpFieldArgs gp_field_args(gpf_handle* h, int which, const double* q) {
-    GpFieldArgs a;
-    a.q = q; a.topo = h->topo; a.Ls = h->Ls; a.L = h->L;
-    FieldPtrs F = field_ptrs(h);
-    a.out0 = a.out1 = nullptr;
-    if (which == 0) a.out0 = F.p;
-    else {
-        const int oi = which == 1 ? 4 : 3;          // Voigt xz / yz (stress.py:91)
-        a.out0 = F.lower + (size_t)oi * h->L.plane;
-        a.out1 = F.upper + (size_t)oi * h->L.plane;
-    }
-    a.blockmax = nullptr;
-    return a;
-}
-
-#define GP_DISPATCH_D(d, ...)                                                                           \
-    switch (d) {                                                                                        \
-    case 1: { constexpr int D_ = 1; __VA_ARGS__; } break;                                               \
-    case 2: { constexpr int D_ = 2; __VA_ARGS__; } break;                                               \
-    case 3: { constexpr int D_ = 3; __VA_ARGS__; } break;                                               \
-    default: { constexpr int D_ = 4; __VA_ARGS__; } break;                                              \
-    }
-
-// posterior mean of model `which` on field q into the derived-field planes; with_grad (pressure only):
-// also *c2_out (device) = max_cells d mean/d rho * Yscale / X_scale[0]
-static int gp_launch_mean(gpf_handle* h, int which, const double* q, bool with_grad, double* c2_out) {
-    auto& g = h->gp[which];
-    GPF_TRY(ensure_fields(h));
-    const Layout& L = h->L;
-    const long long ncell = (long long)(L.Nx + 2) * (L.Ny + 2);
-    const int nb = (int)((ncell + 255) / 256);
-    GpFieldArgs a = gp_field_args(h, which, q);
-    if (with_grad) {
-        GPF_TRY(gp_scratch(h, nb));
-        a.blockmax = h->gpscratch;
-        a.out0 = a.out1 = nullptr;
-    }
-    GP_DISPATCH_D(g.dev.d, {
-        if (with_grad) hipLaunchKernelGGL((k_gp_mean<D_, 1, true>), dim3(nb), dim3(256), 0, h->stream, g.dev, a);
-        else if (g.dev.m == 1) hipLaunchKernelGGL((k_gp_mean<D_, 1, false>), dim3(nb), dim3(256), 0, h->stream, g.dev, a);
-        else hipLaunchKernelGGL((k_gp_mean<D_, 2, false>), dim3(nb), dim3(256), 0, h->stream, g.dev, a);
-    });
-    HIP_TRY(hipGetLastError());
-    if (with_grad) {
-        // dmean/dx_0 in normalised units carries s_0 = inv_scale_0: fscale_0 * X_scale_0; then * Yscale / X_scale_0
-        const double scale = g.dev.fscale[0] * g.dev.yscale;
-        hipLaunchKernelGGL(k_gp_maxreduce, dim3(1), dim3(256), 0, h->stream, h->gpscratch, nb, scale, c2_out);
-        HIP_TRY(hipGetLastError());
-    }
-    return GPF_OK;
-}
-
-extern "C" int gpf_gp_variance(gpf_handle* h, int which, int on_open_step, double* max_var) {
-    if (!h || which < 0 || which > 2) return fail(GPF_ERR_INVALID, "gpf_gp_variance: bad argument");
-    auto& g = h->gp[which];
-    if (!g.set) return fail(GPF_ERR_STATE, "gpf_gp_variance: model not set");
-    if (on_open_step && !h->step_open) return fail(GPF_ERR_STATE, "gpf_gp_variance: no open step");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    void* blas = nullptr;
-    GPF_TRY(gp_blas(h, &blas));
-    RocLibs& R = roclibs();
-    const Layout& L = h->L;
-    int par = 0;
-    GPF_TRY(current_parity(h, &par));
-    const double* q = on_open_step ? h->q[par ^ 1] : h->q[par];
-    const long long ncell = (long long)(L.Nx + 2) * (L.Ny + 2);
-    const int n = g.dev.n;
-    const long long tile = std::max<long long>(256, std::min<long long>(ncell, (64ll << 20) / (8ll * n)));   // <= 64 MiB of Ks
-    const bool use_gemm = g.has_linv;
-    if (h->gptile_doubles < (size_t)(tile * n) * 2) {        // Ks tile + the product tile
-        if (h->gptile) HIP_TRY(hipFree(h->gptile));
-        h->gptile = nullptr;
-        HIP_TRY(hipMalloc(&h->gptile, (size_t)(tile * n) * 2 * 8));
-        h->gptile_doubles = (size_t)(tile * n) * 2;
-    }
-    double* vtile = h->gptile + (size_t)(tile * n);
-    const int nb_total = (int)((ncell + GP_VAR_COLS - 1) / GP_VAR_COLS) + (int)((ncell + tile - 1) / tile) + 8;
-    GPF_TRY(gp_scratch(h, nb_total));
-    GpFieldArgs a = gp_field_args(h, which, q);
-    double* var_plane = h->gpvar + (size_t)which * L.plane;
-    const double one = 1.0;
-    int nbm = 0;
-    for (long long c0 = 0; c0 < ncell; c0 += tile) {
-        const int ncols = (int)std::min<long long>(tile, ncell - c0);
-        GP_DISPATCH_D(g.dev.d, {
-            hipLaunchKernelGGL((k_gp_ks_tile<D_>), dim3((n + 255) / 256, ncols), dim3(256), 0, h->stream, g.dev, a, c0, ncols, h->gptile);
-        });
-        HIP_TRY(hipGetLastError());
-        const double* v = h->gptile;
-        if (use_gemm) {     // V = L^-1 Ks
-            // L^-1 is lower triangular: the upper row block needs only the first half of the columns -> 3/4 of the flops.
-            // (Four row blocks would need 10/16, but 128-row products fill only half of the CUs: measured 56 ms per pass
-            // against 40 ms with two blocks and 46 ms with one.)
-            const double zero = 0.0;
-            const int nblk = n >= 512 ? 2 : 1;
-            const int rows = ((n + nblk - 1) / nblk + 15) / 16 * 16;
-            for (int r0 = 0; r0 < n; r0 += rows) {
-                const int mr = std::min(rows, n - r0), kk = std::min(n, r0 + mr);
-                if (R.gemm(blas, ROC_OP_NONE, ROC_OP_NONE, mr, ncols, kk, &one, g.Linv + r0, n, h->gptile, n, &zero, vtile + r0, n) != 0)
-                    return fail(GPF_ERR_SOLVER, "rocblas_dgemm failed");
-            }
-            v = vtile;
-        } else if (R.trsm(blas, ROC_SIDE_LEFT, ROC_FILL_LOWER, ROC_OP_NONE, ROC_DIAG_NON_UNIT, n, ncols, &one, g.L, n, h->gptile, n) != 0) {
-            return fail(GPF_ERR_SOLVER, "rocblas_dtrsm failed");
-        }
-        const int nb = (ncols + GP_VAR_COLS - 1) / GP_VAR_COLS;
-        hipLaunchKernelGGL(k_gp_var_tile, dim3(nb), dim3(1024), 0, h->stream, v, n, ncols, g.dev.amp,
-                           g.dev.yscale * g.dev.yscale, c0, L, var_plane, h->gpscratch + nbm);
-        HIP_TRY(hipGetLastError());
-        nbm += nb;
-    }
-    double* res = h->gpscratch + h->gpscratch_n;
-    hipLaunchKernelGGL(k_gp_maxreduce, dim3(1), dim3(256), 0, h->stream, h->gpscratch, nbm, 1.0, res);
-    HIP_TRY(hipGetLastError());
-    double mv = 0.0;
-    HIP_TRY(hipMemcpyAsync(&mv, res, 8, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (max_var) *max_var = mv;
-    return GPF_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// the unfused step in pieces, for closures that need the host between stages (GP + active learning)
-// ---------------------------------------------------------------------------------------------
-extern "C" int gpf_open_step(gpf_handle* h) {
-    if (!h) return fail(GPF_ERR_INVALID, "null handle");
-    if (!h->pre_run_done) return fail(GPF_ERR_STATE, "gpf_open_step: call gpf_pre_run first");
-    if (h->step_open) return fail(GPF_ERR_STATE, "gpf_open_step: a step is already open");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    const Layout& L = h->L;
-    GPF_TRY(ensure_fields(h));
-    if (!h->work) HIP_TRY(hipMalloc(&h->work, (size_t)9 * L.plane * sizeof(double)));
-    StepState s;
-    GPF_TRY(read_state(h, s));
-    if (s.invalid) return fail(GPF_ERR_STATE, "gpf_open_step: the state is invalid (rolled back); nothing to advance");
-    h->open_parity = s.parity;
-    hipLaunchKernelGGL(k_copy3, dim3(blocks_for(3 * L.plane)), dim3(256), 0, h->stream, h->q[s.parity], h->q[s.parity ^ 1], 3 * L.plane);
-    HIP_TRY(hipGetLastError());
-    h->step_open = true;
-    h->g1_ready = false;
-    h->host_step = s.step; h->next_step = s.step;
-    return GPF_OK;
-}
-
-extern "C" int gpf_stage_closures(gpf_handle* h) {
-    if (!h || !h->step_open) return fail(GPF_ERR_STATE, "gpf_stage_closures: no open step");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    return launch_fields(h, h->q[h->open_parity ^ 1]);
-}
-
-extern "C" int gpf_stage_advance(gpf_handle* h, int stage) {
-    if (!h || !h->step_open) return fail(GPF_ERR_STATE, "gpf_stage_advance: no open step");
-    if (stage != 0 && stage != 1) return fail(GPF_ERR_INVALID, "gpf_stage_advance: stage must be 0 (predictor) or 1 (corrector)");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    const Layout& L = h->L;
-    double* q = h->q[h->open_parity ^ 1];
-    const long long n = (long long)(L.Nx + 2) * (L.Ny + 2);
-    const int nb = blocks_for(n);
-    double *fx = h->work, *fy = h->work + 3 * L.plane, *src = h->work + 6 * L.plane;
-    FieldPtrs F = field_ptrs(h);
-    const int mc = h->cfg.mc_order;
-    const int sw = mc == 0 ? ((h->host_step % 2 == 0) ? 1 : -1) : mc;
-    const int first = ((sw + 1) / 2) ? 1 : -1;
-    const int dir = stage == 0 ? first : -first;
-    hipLaunchKernelGGL(k_fluxdiff, dim3(nb), dim3(256), 0, h->stream, q, F.p, F.tau, dir, fx, fy, L);
-    hipLaunchKernelGGL(k_source, dim3(nb), dim3(256), 0, h->stream, q, h->topo, F.tau, F.lower, F.upper, src, L);
-    hipLaunchKernelGGL(k_axpy, dim3(nb), dim3(256), 0, h->stream, q, fx, fy, src, h->st, h->cfg.dx, h->cfg.dy, L);
-    hipLaunchKernelGGL(k_bc_x, dim3((L.Ny + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
-    hipLaunchKernelGGL(k_bc_y, dim3((L.Nx + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
-    HIP_TRY(hipGetLastError());
-    return GPF_OK;
-}
-
-extern "C" int gpf_close_step(gpf_handle* h, gpf_scalars_t* out) {
-    if (!h || !h->step_open) return fail(GPF_ERR_STATE, "gpf_close_step: no open step");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    const Layout& L = h->L;
-    double* q = h->q[h->open_parity ^ 1];
-    const double* q0 = h->q[h->open_parity];
-    const long long n = (long long)(L.Nx + 2) * (L.Ny + 2);
-    hipLaunchKernelGGL(k_average, dim3(blocks_for(n)), dim3(256), 0, h->stream, q, q0, L);
-    ScalarPartial* pre = h->spart + h->nspart;
-    ScalarPartial* post = h->spart + h->nspart + 1;
-    GPF_TRY(launch_scalars(h, q, pre, false));          // validity of the averaged field only (problem.py:565)
-    hipLaunchKernelGGL(k_bc_x, dim3((L.Ny + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
-    hipLaunchKernelGGL(k_bc_y, dim3((L.Nx + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
-    GPF_TRY(launch_scalars(h, q, post));                // scalars after the ghost update (problem.py:576-578)
-    hipLaunchKernelGGL(k_commit_unfused, dim3(1), dim3(1), 0, h->stream, h->st, pre, post);
-    HIP_TRY(hipGetLastError());
-    h->step_open = false;
-    StepState s;
-    GPF_TRY(read_state(h, s));
-    h->host_step = s.step; h->next_step = s.step;
-    if (out) fill_scalars(s, nullptr, 0.0, out);
-    return GPF_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// stage-wise step of a slab (GP closures / shear thinning across several GPUs): the rows a neighbour needs
-// travel after EACH stage, the scalars once per step
-// ---------------------------------------------------------------------------------------------
-extern "C" int gpf_stage_message(gpf_handle* h) {
-    if (!h || !h->step_open) return fail(GPF_ERR_STATE, "gpf_stage_message: no open step");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    GPF_TRY(ensure_halo(h));
-    HaloArgs a = halo_args(h, 0, nullptr, -1, -1);
-    a.work_parity = h->open_parity ^ 1;
-    hipLaunchKernelGGL(k_halo_pack, dim3((h->L.pitch + 255) / 256), dim3(256), 0, h->stream, a);
-    HIP_TRY(hipGetLastError());
-    return GPF_OK;
-}
-
-extern "C" int gpf_stage_absorb(gpf_handle* h, const void* gathered, int nranks, int rank_lo, int rank_hi) {
-    if (!h || !gathered || nranks < 1) return fail(GPF_ERR_INVALID, "gpf_stage_absorb: bad argument");
-    if (!h->step_open) return fail(GPF_ERR_STATE, "gpf_stage_absorb: no open step");
-    if (rank_lo >= nranks || rank_hi >= nranks) return fail(GPF_ERR_INVALID, "gpf_stage_absorb: neighbour rank out of range");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    HaloArgs a = halo_args(h, 0, (const double*)gathered, rank_lo, rank_hi);
-    a.work_parity = h->open_parity ^ 1;
-    hipLaunchKernelGGL(k_halo_unpack, dim3((h->L.pitch + 255) / 256), dim3(256), 0, h->stream, a);
-    HIP_TRY(hipGetLastError());
-    return GPF_OK;
-}
-
-// average + validity + ghost rules + this slab's share of the scalars -> record in the message
-extern "C" int gpf_close_step_local(gpf_handle* h) {
-    if (!h || !h->step_open) return fail(GPF_ERR_STATE, "gpf_close_step_local: no open step");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    GPF_TRY(ensure_halo(h));
-    const Layout& L = h->L;
-    double* q = h->q[h->open_parity ^ 1];
-    const double* q0 = h->q[h->open_parity];
-    const long long n = (long long)(L.Nx + 2) * (L.Ny + 2);
-    hipLaunchKernelGGL(k_average, dim3(blocks_for(n)), dim3(256), 0, h->stream, q, q0, L);
-    ScalarPartial* pre = h->spart + h->nspart;
-    ScalarPartial* post = h->spart + h->nspart + 1;
-    GPF_TRY(launch_scalars(h, q, pre, false));
-    hipLaunchKernelGGL(k_bc_x, dim3((L.Ny + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
-    hipLaunchKernelGGL(k_bc_y, dim3((L.Nx + 2 + 255) / 256), dim3(256), 0, h->stream, q, L, h->E);
-    GPF_TRY(launch_scalars(h, q, post));
-    hipLaunchKernelGGL(k_record_unfused, dim3(1), dim3(1), 0, h->stream, pre, post, h->halo + (size_t)6 * L.pitch);
-    HIP_TRY(hipGetLastError());
-    return GPF_OK;
-}
-
-extern "C" int gpf_close_step_commit(gpf_handle* h, const void* gathered, int nranks, gpf_scalars_t* out) {
-    if (!h || !gathered || nranks < 1) return fail(GPF_ERR_INVALID, "gpf_close_step_commit: bad argument");
-    if (!h->step_open) return fail(GPF_ERR_STATE, "gpf_close_step_commit: no open step");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    hipLaunchKernelGGL(k_commit_gathered, dim3(1), dim3(1), 0, h->stream, h->st, (const double*)gathered,
-                       (long long)halo_len(h), (long long)6 * h->L.pitch, nranks, (LogEntry*)nullptr, 0ll, 0ll, 0);
-    HIP_TRY(hipGetLastError());
-    h->step_open = false;
-    StepState s;
-    GPF_TRY(read_state(h, s));
-    h->host_step = s.step; h->next_step = s.step;
-    if (out) fill_scalars(s, nullptr, 0.0, out);
-    return GPF_OK;
-}
-
+// The remaining entry points live in the files included below; they are parts of THIS translation unit (they share
+// the handle and the static helpers above) and are split only for readability.
+#include "api_unfused_step.inc"
+#include "api_operators.inc"
+#include "api_slab_allgather.inc"
+#include "api_elastic.inc"
+#include "api_slab_p2p.inc"
+#include "api_gp.inc"
+#include "api_stagewise.inc"
+#include "api_slab_stagewise.inc"
