@@ -14,6 +14,7 @@ in plain NumPy/SciPy, the arithmetic of the reference path
     GaPFlow/topography.py:38-255 (gap profiles)
     GaPFlow/io.py:128-445        (YAML sanitisation)
     GaPFlow/models/gp.py:509-603 (Matern-3/2 GP surrogate; tinygp semantics)
+    GaPFlow/topography.py:257-280, 327-437 (elastic deformation of the gap; ContactMechanics semantics)
 
 Pinning status
 --------------
@@ -28,4 +29,11 @@ Pinning status
   reference's only numeric GP test is a self-consistency check
   (tests/test_inference.py:88-111).  ``oracle/gp.py`` restates the published
   Matern-3/2 + Cholesky formulas; see its header.
+* Viscous stresses beyond the solver's branch (every slip keyword, gradient
+  terms): PINNED by ``tests/golden/leaf_viscous_slip.npz`` (true outputs of the
+  reference's viscous.py); the oracle derives them from the velocity model.
+* Elastic deformation: PARITY UNPINNED.  ContactMechanics is not installed and
+  the reference has no test or fixture on this path.  ``oracle/elastic.py``
+  restates the published half-space responses and is pinned to analytic
+  solutions in ``tests/test_oracle_elastic.py``; see its header.
 """
