@@ -440,11 +440,19 @@ class SlabProblem:
         if self._writer_problem is None:
             from .problem import Problem
             d = deepcopy(self.input)
+            # with surrogates the writer shares this rank's database and mirrors its models (same data, same
+            # hyper-parameters), so the closures of a frame are the surrogates' means as in a serial run
             self._writer_problem = Problem(d['options'], d['grid'], d['numerics'], d['properties'], d['geometry'],
-                                           device=self._device)
+                                           gp=d.get('gp') if self._gp_models else None,
+                                           database=self.database if self._gp_models else None, device=self._device)
             w = self._writer_problem
             w.history = {k: [] for k in ('step', 'time', 'ekin', 'residual', 'vsound')}
         w = self._writer_problem
+        for name, m in self._gp_models.items():
+            wm = w._gp_models[name]
+            if wm.theta is None or wm.last_fit_train_size != m.last_fit_train_size or not np.array_equal(wm.theta, m.theta):
+                wm.theta, wm.last_fit_train_size = np.array(m.theta), m.last_fit_train_size
+                wm.attach()
         st = self.state()
         w.q[...] = q
         w.step, w.simtime, w.dt, w.residual = int(st.step), st.simtime, st.dt, st.residual
@@ -456,8 +464,6 @@ class SlabProblem:
         import datetime as _dt
         opt, num = self.input['options'], self.input['numerics']
         silent, wf, max_it = opt['silent'], opt['write_freq'], num['max_it']
-        if self._gp_models and not silent:
-            raise NotImplementedError("output frames of a slab run with surrogate closures: set options.silent")
         if not self._pre_run_done:
             self.pre_run()
         if not silent:

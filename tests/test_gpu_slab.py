@@ -248,3 +248,38 @@ def test_slab_run_writes_the_same_files_as_the_serial_run(hiplib, tmp_path, p2p)
             va, vb = fa.variables[name][:], fb.variables[name][:]
             assert va.shape == vb.shape and va.shape[0] == 4
             assert np.abs(va - vb).max() <= 1e-11 * np.abs(vb).max(), name
+
+
+def _slab_gp_run_worker(rank, world, port, text):
+    import torch
+    import torch.distributed as dist
+    from gapflow_amd.slab import SlabProblem
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        st = SlabProblem.from_string(text, device=0, dist=StagedGloo(dist, torch)).run()
+        assert st.step == 6 and st.invalid == 0
+    finally:
+        dist.destroy_process_group()
+
+
+def test_slab_run_with_surrogates_writes_the_same_frames(hiplib, tmp_path):
+    """SlabProblem.run() with GP closures: the frames written by rank 0 (through a whole-domain Problem that mirrors the
+    slab's models) equal those of the serial run."""
+    import torch.multiprocessing as mp
+    from scipy.io import netcdf_file
+    from gapflow_amd import Problem
+    base = GP_SIM.replace('AL_PRESS', 'False').replace('max_it: 100', 'max_it: 6')
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    text = lambda d: base.replace('options: {silent: True, write_freq: 1000}', f'options: {{output: {tmp_path / d}, write_freq: 3, use_tstamp: False}}')
+    mp.spawn(_slab_gp_run_worker, args=(2, port, text('slab')), nprocs=2, join=True)
+    Problem.from_string(text('serial')).run()
+    with netcdf_file(str(tmp_path / 'slab' / 'sol.nc'), mmap=False) as fa, netcdf_file(str(tmp_path / 'serial' / 'sol.nc'), mmap=False) as fb:
+        for name in ('solution', 'pressure', 'wall_stress_xz'):
+            va, vb = fa.variables[name][:], fb.variables[name][:]
+            assert va.shape == vb.shape and va.shape[0] == 3, name          # frames at steps 0, 3, 6
+            assert np.abs(va - vb).max() <= 1e-9 * np.abs(vb).max(), name
