@@ -206,7 +206,7 @@ def run_slabs(args, rank, world):
             "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"2D journal bearing {N_GRID}x{N_GRID}, fixed DH EOS, all-periodic, adaptive CFL 0.5 "
-                                   "(BASELINE.json configs[2])", "slabs": world, "dispatch": mode,
+                                   "(BASELINE.json configs[2])", "slabs": world, "rccl_ranks": dist.get_world_size(), "dispatch": mode,
                        "parallelism": f"{world} x-slabs, one RCCL all-gather (2 halo rows + 64-B record per rank) per step"},
             "roofline": {"bound": "hbm", "achieved": per_gpu, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": per_gpu / HBM_PEAK_GBS, "traffic": None,
@@ -223,30 +223,35 @@ def run_slabs(args, rank, world):
     best = line(wall, "host-dispatched steps, RCCL all-gather")
     st_ref = (int(st.step), float(st.dt), float(st.ekin))
 
-    # Two faster ways to run the same K steps follow.  Neither can be rehearsed across GPUs on the one-GPU development
-    # box, so each runs behind a watchdog and counts only if it finishes, reproduces the run above (same step count,
-    # dt and kinetic energy) on every rank, and is faster.
-    def give_up():              # a wedged exchange cannot be interrupted: report what is already measured
-        if rank == 0:
-            _emit(best)
-        os._exit(0)
+    # Two faster ways to run the same K steps can follow (GPF_BENCH_TRY_P2P=1 / GPF_BENCH_TRY_GRAPH=1; both OFF by default:
+    # neither can be rehearsed across GPUs on the one-GPU development box).  An attempt counts only if it finishes,
+    # reproduces the run above (same step count, dt and kinetic energy) on every rank, and is faster.  An attempt that
+    # fails -- watchdog expiry, Python exception, fatal signal from the GPU runtime -- is NOT success: the line already
+    # measured is still printed, with the failure recorded in "attempt_failures", and the process exits non-zero.
+    failures = []
+    FAILED_RC = 3
 
-    # ... and a GPU fault inside an attempt aborts the process from a runtime thread (SIGABRT): the measurement that
-    # already exists must not die with it.  libc-level handler; the callback only writes the prepared line and exits.
+    def fail_out(name, reason):
+        failures.append({"name": name, "reason": reason})
+        if rank == 0:
+            best["attempt_failures"] = failures
+            _emit(best)
+        os._exit(FAILED_RC)     # peers may be stuck in a collective or a wedged exchange this rank cannot leave cleanly
+
+    current = {"name": None}
+
+    # a GPU fault inside an attempt aborts the process from a runtime thread (SIGABRT): libc-level handler, the callback
+    # only writes the prepared line and exits with the failure status
     import ctypes
     import signal
 
     @ctypes.CFUNCTYPE(None, ctypes.c_int)
     def on_fatal(signum):
-        if rank == 0:
-            _emit(best)
-        os._exit(0)
+        fail_out(current["name"] or "attempt", f"fatal signal {signum} in the attempt")
     _keep_alive.append(on_fatal)
     libc = ctypes.CDLL(None)
     libc.signal.restype = ctypes.c_void_p
     libc.signal.argtypes = [ctypes.c_int, ctypes.c_void_p]
-    for sig in (signal.SIGABRT, signal.SIGSEGV, signal.SIGBUS):
-        libc.signal(int(sig), ctypes.cast(on_fatal, ctypes.c_void_p))
 
     def same_run(s2, steps):
         ok = (int(s2.step) == steps and s2.invalid == 0 and abs(s2.dt - st_ref[1]) <= 1e-12 * st_ref[1]
@@ -256,20 +261,24 @@ def run_slabs(args, rank, world):
         return float(t.item()) == 1.0
 
     def attempt(name, fn):
-        nonlocal best
-        dog = threading.Timer(float(os.environ.get('GPF_BENCH_ATTEMPT_TIMEOUT', 120)), give_up)
+        current["name"] = name
+        limit = float(os.environ.get('GPF_BENCH_ATTEMPT_TIMEOUT', 120))
+        dog = threading.Timer(limit, fail_out, args=(name, f"watchdog: no result after {limit:.0f} s"))
         dog.daemon = True
         dog.start()
+        for sig in (signal.SIGABRT, signal.SIGSEGV, signal.SIGBUS):
+            libc.signal(int(sig), ctypes.cast(on_fatal, ctypes.c_void_p))
         try:
             with contextlib.redirect_stdout(sys.stderr):
                 fn()
-        except Exception as e:      # noqa: BLE001 -- any failure here leaves the measured line standing
-            print(f"[bench] {name} not used: {type(e).__name__}: {e}", file=sys.stderr)
+        except Exception as e:      # noqa: BLE001
             dog.cancel()
-            if rank == 0:
-                _emit(best)
-            os._exit(0)             # peers may be stuck in a collective this rank will never join
+            print(f"[bench] {name} failed: {type(e).__name__}: {e}", file=sys.stderr)
+            fail_out(name, f"{type(e).__name__}: {e}")
         dog.cancel()
+        for sig in (signal.SIGABRT, signal.SIGSEGV, signal.SIGBUS):
+            libc.signal(int(sig), None)                     # SIG_DFL again
+        current["name"] = None
 
     def try_p2p():
         # the step's own kernels write rows and records into the peers' IPC-mapped mailboxes (gapflow_amd/slab.py)
@@ -301,12 +310,11 @@ def run_slabs(args, rank, world):
             cand["config"]["eager_ms_per_step"] = wall / args.steps * 1e3
             best = cand
 
-    if os.environ.get('GPF_BENCH_TRY_P2P', '1') == '1':
+    if os.environ.get('GPF_BENCH_TRY_P2P', '0') == '1':
         attempt("peer-to-peer transport", try_p2p)
-    if os.environ.get('GPF_BENCH_TRY_GRAPH', '1') == '1':
+    if os.environ.get('GPF_BENCH_TRY_GRAPH', '0') == '1':
         attempt("graph replay", try_graph)
-    for sig in (signal.SIGABRT, signal.SIGSEGV, signal.SIGBUS):
-        libc.signal(int(sig), None)                         # SIG_DFL again
+    best["attempt_failures"] = failures
     dist.barrier()
     dist.destroy_process_group()
     return best if rank == 0 else None

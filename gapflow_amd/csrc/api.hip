@@ -9,8 +9,10 @@
 #include <vector>
 
 #include "../../include/gapflow_hip.h"
+#include "phys_setup.hpp"
 #include "step_kernel.hip"
 #include "aux_kernels.hip"
+#include "step2_kernel.hip"
 #include "gp_kernels.hip"
 #include "elastic_kernels.hip"
 #include "small_kernel.hip"
@@ -40,6 +42,8 @@ static int fail(int code, const std::string& msg) {
     } while (0)
 
 static_assert(sizeof(LogEntry) == sizeof(gpf_scalars_t), "LogEntry must mirror gpf_scalars_t");
+// k_step2's 16-byte pair loads may reach one pair past the last column of the last row of a buffer
+static constexpr size_t PLANE_PAD_BYTES = 256;
 
 struct gpf_handle {
     gpf_config cfg;
@@ -101,77 +105,16 @@ struct gpf_handle {
     long long next_step = 0;                // index of the next step to be enqueued (== device step unless halted)
     bool plan_valid = false;                // rows_per_chunk / nchunks fitted to the step kernel's residency
     int max_chunks = 0;
+    // two-columns-per-lane step kernel (step2_kernel.hip): window geometry per predictor direction [0: D=+1, 1: D=-1],
+    // row chunks, grid; `fused`: ghost cells, stage-1 ghost data and the commit happen inside the kernel (no slab halo)
+    Strip2Geom geom2[2];
+    int nchunks2 = 0, nblocks2 = 0, npartials2_cap = 0, nblock_partials_cap = 0;
+    bool plan2_valid = false;
 };
 
 // ---------------------------------------------------------------------------------------------
 static void make_phys(const gpf_config& c, Phys& P) {
-    std::memset(&P, 0, sizeof(P));
-    P.U = c.U; P.V = c.V; P.eta = c.eta; P.zeta = c.zeta;
-    P.v1 = c.zeta + (4.0 / 3.0) * c.eta; P.v2 = c.zeta - (2.0 / 3.0) * c.eta;      // viscous.py:82-83
-    P.inv_dx = 1.0 / c.dx; P.inv_dy = 1.0 / c.dy;
-    P.eos = c.eos; P.piezo = c.piezo;
-    const double* e = c.eos_par;
-    switch (c.eos) {
-    case GPF_EOS_DH:     // rho0, P0, C1, C2
-        P.e[0] = e[0]; P.e[1] = e[1]; P.e[2] = e[2]; P.e[3] = e[3];
-        P.e[4] = 0.99 * e[3] * e[0]; P.e[5] = 1.0 / e[0]; P.e[6] = e[2] * e[0] * (e[3] - 1.0); P.e[7] = e[3] * e[0];
-        break;
-    case GPF_EOS_PL:     // rho0, P0, alpha
-        P.e[0] = e[0]; P.e[1] = e[1]; P.e[2] = e[2]; P.e[3] = 1.0 / (1.0 - 0.5 * e[2]);
-        break;
-    case GPF_EOS_VDW:    // M, T, a, b   (pressure.py:168-173)
-        P.e[0] = 1000.0 / e[0]; P.e[1] = 8.31446261815324 * e[1]; P.e[2] = e[2] / 10.0; P.e[3] = e[3] / 1000.0;
-        break;
-    case GPF_EOS_MT:     // rho0, P0, K, n
-    case GPF_EOS_CUBIC:  // a, b, c, d
-        for (int i = 0; i < 4; ++i) P.e[i] = e[i];
-        break;
-    case GPF_EOS_BWR: {  // T, gamma; x1..x32 of Johnson, Zollweg & Gubbins (1993), pressure.py:255-272
-        static const double x[32] = {
-            0.8623085097507421, 2.976218765822098, -8.402230115796038, 0.1054136629203555, -0.8564583828174598,
-            1.582759470107601, 0.7639421948305453, 1.753173414312048, 2.798291772190376e+03, -4.8394220260857657e-02,
-            0.9963265197721935, -3.698000291272493e+01, 2.084012299434647e+01, 8.305402124717285e+01,
-            -9.574799715203068e+02, -1.477746229234994e+02, 6.398607852471505e+01, 1.603993673294834e+01,
-            6.805916615864377e+01, -2.791293578795945e+03, -6.245128304568454, -8.116836104958410e+03,
-            1.488735559561229e+01, -1.059346754655084e+04, -1.131607632802822e+02, -8.867771540418822e+03,
-            -3.986982844450543e+01, -4.689270299917261e+03, 2.593535277438717e+02, -2.694523589434903e+03,
-            -7.218487631550215e+02, 1.721802063863269e+02};
-        const double T = e[0], T2 = T * T, T3 = T2 * T, T4 = T2 * T2;
-        P.e[0] = e[1];
-        P.x[0] = T;
-        P.x[1] = x[0] * T + x[1] * std::sqrt(T) + x[2] + x[3] / T + x[4] / T2;
-        P.x[2] = x[5] * T + x[6] + x[7] / T + x[8] / T2;
-        P.x[3] = x[9] * T + x[10] + x[11] / T;
-        P.x[4] = x[12];
-        P.x[5] = x[13] / T + x[14] / T2;
-        P.x[6] = x[15] / T;
-        P.x[7] = x[16] / T + x[17] / T2;
-        P.x[8] = x[18] / T2;
-        P.x[9] = x[19] / T2 + x[20] / T3;
-        P.x[10] = x[21] / T2 + x[22] / T4;
-        P.x[11] = x[23] / T2 + x[24] / T3;
-        P.x[12] = x[25] / T2 + x[26] / T4;
-        P.x[13] = x[27] / T2 + x[28] / T3;
-        P.x[14] = x[29] / T2 + x[30] / T3 + x[31] / T4;
-        break;
-    }
-    case GPF_EOS_BAYADA: {   // rho_l, rho_v, c_l, c_v (pressure.py:303-304)
-        const double rl = e[0], rv = e[1], cl2 = e[2] * e[2], cv2 = e[3] * e[3];
-        const double N = rv * cv2 * rl * cl2 * (rv - rl) / (rv * rv * cv2 - rl * rl * cl2);
-        const double Pcav = rv * cv2 - N * std::log(rv * rv * cv2 / (rl * rl * cl2));
-        P.e[0] = rl; P.e[1] = rv; P.e[2] = cl2; P.e[3] = cv2; P.e[4] = N; P.e[5] = Pcav; P.e[6] = 1.0 / (rv - rl);
-        break;
-    }
-    }
-    const double* z = c.piezo_par;
-    switch (c.piezo) {
-    case GPF_PIEZO_BARUS: P.pz[0] = z[0]; break;
-    case GPF_PIEZO_ROELANDS: P.pz[0] = z[0]; P.pz[1] = z[1]; P.pz[2] = z[2]; P.pz[3] = std::log(c.eta / z[0]); break;
-    case GPF_PIEZO_DUKLER:
-    case GPF_PIEZO_MCADAMS: P.pz[0] = z[0]; P.pz[1] = z[1]; P.pz[2] = z[2]; break;
-    }
-    P.thinning = c.thinning;
-    for (int i = 0; i < 4; ++i) P.th[i] = c.thinning_par[i];
+    setup_phys(P, c.U, c.V, c.eta, c.zeta, c.dx, c.dy, c.eos, c.eos_par, c.piezo, c.piezo_par, c.thinning, c.thinning_par);
 }
 
 static int blocks_for(long long n, int bs = 256, int cap = 4096) {
@@ -262,11 +205,11 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
             return cleanup(fail(GPF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)));      \
     } while (0)
     for (int b = 0; b < 2; ++b) {
-        HIP_TRY_C(hipMalloc(&h->q[b], 3 * plane_b));
-        HIP_TRY_C(hipMemset(h->q[b], 0, 3 * plane_b));
+        HIP_TRY_C(hipMalloc(&h->q[b], 3 * plane_b + PLANE_PAD_BYTES));
+        HIP_TRY_C(hipMemset(h->q[b], 0, 3 * plane_b + PLANE_PAD_BYTES));
     }
-    HIP_TRY_C(hipMalloc(&h->topo, 3 * plane_b));
-    HIP_TRY_C(hipMemset(h->topo, 0, 3 * plane_b));
+    HIP_TRY_C(hipMalloc(&h->topo, 3 * plane_b + PLANE_PAD_BYTES));
+    HIP_TRY_C(hipMemset(h->topo, 0, 3 * plane_b + PLANE_PAD_BYTES));
     const size_t g1n = (size_t)3 * L.pitch + (size_t)3 * (L.Nx + 2);
     HIP_TRY_C(hipMalloc(&h->g1, g1n * sizeof(double)));
     HIP_TRY_C(hipMemset(h->g1, 0, g1n * sizeof(double)));
@@ -367,7 +310,7 @@ extern "C" int gpf_upload(gpf_handle* h, int field, const double* host, size_t c
         bool nz = false;
         for (size_t i = 0; i < count && !nz; ++i) nz = host[i] != 0.0;
         if (!nz && !h->Ls) return GPF_OK;      // Ls == 0 everywhere: the HAS_LS=false kernels apply
-        if (!h->Ls) { HIP_TRY(hipMalloc(&h->Ls, (size_t)L.plane * sizeof(double))); h->plan_valid = false; }
+        if (!h->Ls) { HIP_TRY(hipMalloc(&h->Ls, (size_t)L.plane * sizeof(double) + PLANE_PAD_BYTES)); h->plan_valid = false; h->plan2_valid = false; }
         HIP_TRY(hipMemsetAsync(h->Ls, 0, (size_t)L.plane * sizeof(double), h->stream));
         dst = h->Ls;
     }
@@ -385,7 +328,7 @@ extern "C" int gpf_upload(gpf_handle* h, int field, const double* host, size_t c
                 }
             }
         const int mode = xonly ? 1 : (yonly ? 2 : 0);
-        if (mode != h->topo_mode) h->plan_valid = false;
+        if (mode != h->topo_mode) { h->plan_valid = false; h->plan2_valid = false; }
         h->topo_mode = h->el.on ? 0 : mode;         // an elastic gap changes on the device: always read the planes
         if (mode) {
             const int n = mode == 1 ? nx : ny;
@@ -641,6 +584,101 @@ static int plan_step(gpf_handle* h) {
     return GPF_OK;
 }
 
+// ---- two-columns-per-lane step kernel (step2_kernel.hip) ----
+typedef void (*step2_kernel_t)(const Step2Args, const Phys);
+
+static step2_kernel_t step2_kernel(int eos, bool has_ls, bool piezo, int D, int topo_mode) {
+    step2_kernel_t k = nullptr;
+    EOS_DISPATCH(eos, {
+        if (piezo) {
+            if (has_ls) k = D > 0 ? k_step2<EOS_, true, true, 1, 0> : k_step2<EOS_, true, true, -1, 0>;
+            else k = D > 0 ? k_step2<EOS_, false, true, 1, 0> : k_step2<EOS_, false, true, -1, 0>;
+        } else if (has_ls) {
+            k = D > 0 ? k_step2<EOS_, true, false, 1, 0> : k_step2<EOS_, true, false, -1, 0>;
+        } else if (topo_mode == 1) {
+            k = D > 0 ? k_step2<EOS_, false, false, 1, 1> : k_step2<EOS_, false, false, -1, 1>;
+        } else if (topo_mode == 2) {
+            k = D > 0 ? k_step2<EOS_, false, false, 1, 2> : k_step2<EOS_, false, false, -1, 2>;
+        } else {
+            k = D > 0 ? k_step2<EOS_, false, false, 1, 0> : k_step2<EOS_, false, false, -1, 0>;
+        }
+    });
+    return k;
+}
+
+// Window geometry of k_step2 for predictor direction D (see Strip2Geom).  Logical column m sits at physical column
+// iy = m (D > 0) or Ny+1-m (D < 0), i.e. at element off + iy of its row with off = 15: a lane's pair must start on an
+// odd physical column.  D > 0: w0 odd.  D < 0: the pair (m, m+1) starts at iy = Ny - m, odd iff m and Ny differ in
+// parity, so w0 is odd for even Ny and even for odd Ny.  Shifting w0 by -4 keeps the alignment and moves column Ny
+// from window positions 123..126 (no room for the two wrap lanes behind the ghost column) to 1..4 of the next strip.
+static Strip2Geom strip2_geom(const Layout& L, int D) {
+    Strip2Geom G;
+    const int e = (D < 0 && (L.Ny & 1)) ? 1 : 0;
+    for (int k = 0; k < 2; ++k) {
+        G.w0 = -1 - e - 4 * k;
+        G.s_ghost = (L.Ny - G.w0 - 1) / STRIP2;
+        const int p_ny = L.Ny - G.w0 - STRIP2 * G.s_ghost;       // 1..126
+        G.lane_ghost = (p_ny + 1) >> 1; G.slot_ghost = (p_ny + 1) & 1;
+        if (G.lane_ghost + 2 <= 63) break;
+    }
+    G.nstrips = G.s_ghost + 1;
+    G.lane_wrap = G.lane_ghost + 1;
+    const int p0 = -G.w0;                                       // window position of logical column 0 in strip 0
+    G.wrap_ma = (p0 % 2 == 0) ? 0 : -1;
+    const int d = 1 - G.wrap_ma;                                // logical column 1 relative to the first wrap lane
+    G.wrap_src_lane = G.lane_wrap + d / 2; G.wrap_src_slot = d & 1;
+    return G;
+}
+
+static bool use_step2() {
+    static const bool off = std::getenv("GPF_STEP_KERNEL") && std::atoi(std::getenv("GPF_STEP_KERNEL")) == 1;
+    return !off;
+}
+// ghost cells, stage-1 ghost data and the commit inside k_step2: every handle that is not a slab
+static bool step2_fused(const gpf_handle* h) {
+    static const bool off = std::getenv("GPF_STEP_UNFUSED_EDGES") != nullptr;
+    return !off && h->E.halo[0] == 0 && h->E.halo[1] == 0;
+}
+
+// One wave marches over one row chunk of one 126-column strip; the chunks are sized so that all waves are resident at
+// once (a single round, no tail) when the problem is big enough.
+static int plan_step2(gpf_handle* h) {
+    if (h->plan2_valid) return GPF_OK;
+    const Layout& L = h->L;
+    h->geom2[0] = strip2_geom(L, 1);
+    h->geom2[1] = strip2_geom(L, -1);
+    const int nstrips = std::max(h->geom2[0].nstrips, h->geom2[1].nstrips);
+    int nchunks = 0;
+    if (const char* s = std::getenv("GPF_CHUNKS")) nchunks = std::atoi(s);
+    if (nchunks <= 0) {
+        int per_cu = 0, ncu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)step2_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, 1, topo_mode_of(h)), 256, 0));
+        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->cfg.device));
+        const int resident_waves = std::max(1, per_cu * ncu) * 4;
+        nchunks = resident_waves / nstrips;
+    }
+    nchunks = std::max(1, std::min(nchunks, std::max(1, L.Nx / 4)));        // small grids: >= 4 rows per chunk
+    h->nchunks2 = nchunks;
+    const int nwaves = nstrips * nchunks;
+    h->nblocks2 = (((nwaves + 3) / 4) + 7) / 8 * 8;
+    if (nwaves > h->npartials2_cap) {
+        if (h->partials) HIP_TRY(hipFree(h->partials));
+        h->partials = nullptr;
+        HIP_TRY(hipMalloc(&h->partials, (size_t)nwaves * sizeof(Partial)));
+        HIP_TRY(hipMemset(h->partials, 0, (size_t)nwaves * sizeof(Partial)));
+        h->npartials2_cap = nwaves; h->npartials = std::max(h->npartials, nwaves);
+    }
+    if (h->nblocks2 > h->nblock_partials_cap) {
+        const int cap = std::max(1024, h->nblocks2);
+        if (h->block_partials) HIP_TRY(hipFree(h->block_partials));
+        h->block_partials = nullptr;
+        HIP_TRY(hipMalloc(&h->block_partials, (size_t)cap * sizeof(Partial)));
+        h->nblock_partials_cap = cap;
+    }
+    h->plan2_valid = true;
+    return GPF_OK;
+}
+
 static P2PArgs p2p_args(gpf_handle* h, bool on) {
     P2PArgs c;
     c.on = on ? 1 : 0; c.nranks = h->p2p.nranks; c.rank = h->p2p.rank; c.rank_lo = h->p2p.rank_lo; c.rank_hi = h->p2p.rank_hi;
@@ -667,11 +705,21 @@ static int ghost_args(gpf_handle* h, int honor_stop, GhostArgs& g) {
 static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, double* slab_out,
                         hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, bool p2p = false) {
     const Layout& L = h->L;
-    GPF_TRY(plan_step(h));
+    const bool two = use_step2();
+    if (two) GPF_TRY(plan_step2(h));
+    else GPF_TRY(plan_step(h));
     const int mc = h->cfg.mc_order;
     const int D = mc == 0 ? ((h->next_step % 2 == 0) ? 1 : -1) : (((mc + 1) / 2) ? 1 : -1);
     h->next_step += 1;
-    const int np_step = h->nstrips * h->nchunks;
+    const bool fused = two && step2_fused(h) && slab_out == nullptr && !p2p;
+    const Strip2Geom& G2 = h->geom2[D > 0 ? 0 : 1];
+    const int np_step = two ? G2.nstrips * h->nchunks2 : h->nstrips * h->nchunks;
+    Step2Args a2;
+    a2.qa = h->q[0]; a2.qb = h->q[1]; a2.topo = h->topo; a2.topo_line = h->topo_line; a2.Ls = h->Ls;
+    a2.g1x = h->g1; a2.g1y = h->g1 + 3 * L.pitch;
+    a2.st = h->st; a2.partials = h->partials; a2.block_partials = h->block_partials; a2.arrive = h->arrive;
+    a2.log = h->log; a2.log_base = log_base; a2.log_cap = h->log_cap;
+    a2.L = L; a2.E = h->E; a2.G = G2; a2.nchunks = h->nchunks2; a2.fused = fused ? 1 : 0; a2.honor_stop = honor_stop;
     StepArgs a;
     a.qa = h->q[0]; a.qb = h->q[1]; a.topo = h->topo; a.topo_line = h->topo_line; a.Ls = h->Ls;
     a.g1x = h->g1; a.g1y = h->g1 + 3 * L.pitch;
@@ -699,7 +747,7 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     //   peer-to-peer slabs: k_begin_slab (wait for the peers' rows and records, commit, k_ghost_stage1's job for the
     //                   next step) takes the place of the next step's k_ghost_stage1
     const int ntiles = (L.Nx + L.Ny + 63) / 64;                 // stage-1 ghost work: 64 items per block
-    const dim3 ggrid(std::min(ntiles, 512)), sgrid((h->nstrips + 3) / 4, h->nchunks);
+    const dim3 ggrid(std::min(ntiles, 512)), sgrid((h->nstrips + 3) / 4, std::max(1, h->nchunks));
     const step_kernel_t kstep = step_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, D, topo_mode_of(h));
     const int nsend = slab ? std::min((6 * L.pitch + 1023) / 1024, 256) : 0;        // block_partials holds 1024
     WaitArgs w;
@@ -707,13 +755,28 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     w.L = L; w.E = h->E; w.honor_stop = honor_stop; w.arrive = h->arrive + 1; w.p2p = f.p2p;
     w.gathered = nullptr; w.msg_len = 0; w.nranks = 0; w.rank_lo = w.rank_hi = -1;
     const bool has_ls = h->Ls != nullptr;
+    if (fused) {
+        // the whole step in one launch (step2_kernel.hip)
+        const step2_kernel_t k2 = step2_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, D, topo_mode_of(h));
+        if (ev0) hipEventRecord(ev0, h->stream);
+        hipLaunchKernelGGL(k2, dim3(h->nblocks2), dim3(256), 0, h->stream, a2, h->P);
+        if (ev1) hipEventRecord(ev1, h->stream);
+        h->g1_ready = false;
+        HIP_TRY(hipGetLastError());
+        return GPF_OK;
+    }
     EOS_DISPATCH(h->cfg.eos, {
         if (!h->g1_ready) {
             if (has_ls) hipLaunchKernelGGL((k_ghost_stage1<EOS_, true>), ggrid, dim3(256), 0, h->stream, g, h->P);
             else hipLaunchKernelGGL((k_ghost_stage1<EOS_, false>), ggrid, dim3(256), 0, h->stream, g, h->P);
         }
         if (ev0) hipEventRecord(ev0, h->stream);
-        hipLaunchKernelGGL(kstep, sgrid, dim3(256), 0, h->stream, a, h->P);
+        if (two) {
+            const step2_kernel_t k2 = step2_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, D, topo_mode_of(h));
+            hipLaunchKernelGGL(k2, dim3(h->nblocks2), dim3(256), 0, h->stream, a2, h->P);
+        } else {
+            hipLaunchKernelGGL(kstep, sgrid, dim3(256), 0, h->stream, a, h->P);
+        }
         if (ev1) hipEventRecord(ev1, h->stream);
         hipLaunchKernelGGL((k_ghost_fill<EOS_>), dim3(h->nghost_blocks + nsend), dim3(256), 0, h->stream, gf, f, h->nghost_blocks, h->P);
         if (p2p) {                          // wait for the peers, commit, stage-1 ghost data of the next step

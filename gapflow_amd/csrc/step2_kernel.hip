@@ -1,0 +1,486 @@
+// Fused MacCormack step, second generation: two columns per lane, 16-byte accesses, ONE launch per step.
+//
+// Same arithmetic and the same composed radius-1 stencil as step_kernel.hip (see the header there for the
+// reference lines it replaces: problem.py:528-563, stress.py:289-622, integrate.py:38-130, problem.py:319-357,
+// 571-586, 676-768).  What changed is the mapping to the machine:
+//
+//   * a wavefront owns a window of 128 consecutive columns -- lane l holds the pair (2l, 2l+1) of the window --
+//     and produces 126 of them; every global access is ONE 16-byte load/store per lane (1 KB per wave
+//     instruction) on a 16-byte boundary.  Half of the y-neighbours are the lane's own second column, the
+//     other half one DPP/permute away: 6 cross-lane moves per row for 2 cells instead of 6 per cell.
+//   * the strip halo drops from 2/64 to 2/128 columns, and the blocks are numbered so that neighbouring strips
+//     run on the same XCD (blocks are dealt round-robin over the 8 XCDs, each with its own L2): the shared
+//     halo lines are L2 hits instead of second HBM fetches.
+//   * single-handle problems need no other launch: the wave that finishes the row next to an edge also writes
+//     the ghost cells derived from it (problem.py:676-768, corners as rule_y(rule_x(.))), the waves of the last
+//     row chunk / the last strip form the stage-1 field on the downwind ghost row / column themselves
+//     (problem.py:560), and the last workgroup to finish reduces the per-block records and commits dt,
+//     residual and step count on the device (problem.py:571-586).
+//   * slabs (halo rows filled by a neighbour exchange) run the same kernel with `fused = 0`: ghost data comes
+//     from g1x / g1y and the edge kernels of step_kernel.hip / aux_kernels.hip follow as before.
+//
+// Logical indices as in step_kernel.hip: n (rows) and m (columns) increase DOWNWIND of the predictor,
+//   ix = n for D = +1, Nx+1-n for D = -1, likewise iy from m.
+//
+// Included by api.hip after step_kernel.hip (ghost_rule, halted, predictor_direction) and aux_kernels.hip (Acc,
+// block_reduce, publish_partial, merge_published, commit_step).
+#include <hip/hip_runtime.h>
+#include "device_types.hpp"
+
+namespace gpf {
+
+constexpr int STRIP2 = 126;     // output columns per wavefront
+#ifndef GPF_K2_DEPTH
+#define GPF_K2_DEPTH 2          // rows in flight ahead of the one being computed
+#endif
+#ifndef GPF_K2_MINWAVES
+#define GPF_K2_MINWAVES 2       // waves per SIMD the register allocation is held to
+#endif
+
+// Where the windows sit, per predictor direction (host: strip2_geom in api.hip).
+//   logical column of window position p of strip s:  m = w0 + 126 s + p,  p = 2 lane + slot
+// w0 is chosen so that (a) every lane's pair starts on a 16-byte boundary in memory for this direction and
+// (b) the strip that produces column Ny has two idle lanes behind the ghost column Ny+1 ("wrap lanes").
+struct Strip2Geom {
+    int w0;
+    int nstrips;
+    int s_ghost, lane_ghost, slot_ghost;    // strip / lane / slot of logical column Ny+1 (the downwind ghost column)
+    int lane_wrap;                          // first of the two wrap lanes of strip s_ghost
+    int wrap_ma;                            // logical column of slot 0 of lane_wrap (0 or -1: the pair holding column 0)
+    int wrap_src_lane, wrap_src_slot;       // where logical column 1 sits among the wrap lanes
+};
+
+struct Step2Args {
+    const double* qa; const double* qb;
+    const double* topo; const double* topo_line; const double* Ls;
+    const double* g1x; const double* g1y;   // slabs: stage-1 ghost data prepared by k_ghost_stage1 / k_begin_slab
+    StepState* st;
+    Partial* partials;                      // fused = 0: one record per wave (chunk-major), folded by k_ghost_fill
+    Partial* block_partials;                // fused = 1: one record per block, folded by the last block
+    unsigned int* arrive;
+    LogEntry* log; long long log_base, log_cap;
+    Layout L; Edges E; Strip2Geom G;
+    int nchunks;
+    int fused;
+    int honor_stop;
+};
+
+// cross-lane moves by one lane in the whole wavefront (GFX9 DPP wave shifts: a VALU move, no LDS round trip)
+__device__ __forceinline__ double lane_from_below(double v) {          // lane l receives lane l-1's value
+#ifdef GPF_SHUFFLE_BPERMUTE
+    return __shfl_up(v, 1);
+#else
+    const long long b = __double_as_longlong(v);
+    int lo = (int)b, hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);   // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+#endif
+}
+__device__ __forceinline__ double lane_from_above(double v) {          // lane l receives lane l+1's value
+#ifdef GPF_SHUFFLE_BPERMUTE
+    return __shfl_down(v, 1);
+#else
+    const long long b = __double_as_longlong(v);
+    int lo = (int)b, hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);   // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+#endif
+}
+
+// two adjacent cells of one row, as one lane holds them
+struct Row2 { double rho[2], jx[2], jy[2], h[2], hx[2], hy[2], Ls[2]; };
+
+// running reductions of one lane over the cells it wrote (ghost cells included, problem.py:342-347)
+template <int EOS>
+struct Red {
+    double ekin, v2, c2;
+    int flags;
+    __device__ __forceinline__ void init() { ekin = 0.0; v2 = 0.0; c2 = (EOS == EOS_DH) ? __builtin_inf() : 0.0; flags = 0; }
+    // Flags instead of NaN-propagating maxima (see step_kernel.hip): a NaN in any component makes v2 NaN (flag 1);
+    // an imaginary sound speed raises flag 4 and commit_step turns c2max into NaN like np.sqrt(...).max().
+    __device__ __forceinline__ void cell(double r, double jx, double jy, double w, const Phys& P) {
+        const double v = (jx * jx + jy * jy) * rcp(r);
+        ekin += w * (v * 0.5);
+        v2 = fmax(v2, v);
+        if (v != v) flags |= 1;
+        if (r < 0.0) flags |= 2;
+        if (EOS == EOS_DH) {
+            // dp/drho = K / (C2 rho0 - rho)^2 peaks at the cell nearest the pole: one reciprocal per wave at the end
+            c2 = fmin(c2, fabs(P.e[7] - r));
+        } else {
+            const double c = eos_c2<EOS>(r, P);
+            if (!(c >= 0.0)) flags |= 4;
+            c2 = fmax(c2, c);
+        }
+    }
+};
+
+template <int EOS, bool HAS_LS, bool PIEZO, int D, int TOPO>
+__device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, const double* __restrict__ qin,
+                                            double* __restrict__ qout, int strip, int chunk, int lane,
+                                            double (*stash)[128], Acc& result) {
+    const Layout L = a.L;
+    const Strip2Geom G = a.G;
+    const bool fused = a.fused != 0;
+
+    // ---- columns of this lane ----
+    const bool y_periodic = a.E.rule[2][0] == BC_P;
+    const bool ghost_strip = strip == G.s_ghost;                                // wave-uniform
+    const bool wrap_strip = fused && y_periodic && ghost_strip;
+    const bool wrap_lane = wrap_strip && (lane == G.lane_wrap || lane == G.lane_wrap + 1);
+    const int ma = wrap_lane ? G.wrap_ma + 2 * (lane - G.lane_wrap) : G.w0 + strip * STRIP2 + 2 * lane;
+    const int iy_lo_raw = D > 0 ? ma : L.Ny - ma;                               // lower physical column of the pair (odd)
+    const bool lane_ok = iy_lo_raw >= -1 && iy_lo_raw <= L.Ny + 1;
+    const int iy_lo = lane_ok ? iy_lo_raw : -1;                                 // idle lanes read the pair (-1, 0)
+    const int iy0 = D > 0 ? iy_lo : iy_lo + 1, iy1 = D > 0 ? iy_lo + 1 : iy_lo; // physical column of slot 0 / 1
+    const bool out0 = lane_ok && !wrap_lane && lane >= 1 && ma >= 1 && ma <= L.Ny;
+    const bool out1 = lane_ok && !wrap_lane && lane <= 62 && ma + 1 >= 1 && ma + 1 <= L.Ny;
+    const bool is_ghost_lane = ghost_strip && lane == G.lane_ghost;
+    // source of the ghost column's stage-1 value (fused): periodic -> logical column 1 among the wrap lanes,
+    // otherwise logical column Ny, the slot just upwind of the ghost slot
+    const int gsrc_lane = y_periodic ? G.wrap_src_lane : (G.slot_ghost ? G.lane_ghost : G.lane_ghost - 1);
+    const int gsrc_slot = y_periodic ? G.wrap_src_slot : (G.slot_ghost ? 0 : 1);
+
+    // ---- rows of this chunk: outputs n_first..n_last, marching n_first-1 .. n_last+1 ----
+    const int n_first = 1 + (int)(((long long)chunk * L.Nx) / a.nchunks);
+    const int n_last = (int)(((long long)(chunk + 1) * L.Nx) / a.nchunks);
+    const int e_dw_x = D > 0 ? 1 : 0, e_dw_y = D > 0 ? 3 : 2;                    // downwind edges
+    const bool dw_row_is_ghost = (n_last == L.Nx) && a.E.halo[e_dw_x] != 1;
+    const bool x_periodic = a.E.rule[0][0] == BC_P;
+
+    const double dt = a.st->dt;
+    const double cx = (double)D * P.inv_dx, cy = (double)D * P.inv_dy;
+
+    const double* __restrict__ q0p = qin;
+    const double* __restrict__ q1p = qin + L.plane;
+    const double* __restrict__ q2p = qin + 2 * L.plane;
+    const double* __restrict__ hp = a.topo;
+    const double* __restrict__ hxp = a.topo + L.plane;
+    const double* __restrict__ hyp = a.topo + 2 * L.plane;
+    double* __restrict__ qo0 = qout;
+    double* __restrict__ qo1 = qout + L.plane;
+    double* __restrict__ qo2 = qout + 2 * L.plane;
+
+    // TOPO as in step_kernel.hip: 1 = one (h, hx, hy) triple per ROW through the scalar cache, 2 = the lane's two
+    // column triples stay in registers for the whole march; the values are bitwise those of the planes.
+    double lh[2] = {0.0, 0.0}, lhx[2] = {0.0, 0.0}, lhy[2] = {0.0, 0.0};
+    if (TOPO == 2) {
+        const int c0 = min(max(iy0, 0), L.Ny + 1), c1 = min(max(iy1, 0), L.Ny + 1);
+        lh[0] = a.topo_line[c0]; lhx[0] = a.topo_line[(L.Ny + 2) + c0]; lhy[0] = a.topo_line[2 * (L.Ny + 2) + c0];
+        lh[1] = a.topo_line[c1]; lhx[1] = a.topo_line[(L.Ny + 2) + c1]; lhy[1] = a.topo_line[2 * (L.Ny + 2) + c1];
+    }
+    // Addressing: the row base is wave-uniform (scalar registers), the lane adds a constant 32-bit byte offset --
+    // the `global_load_dwordx4 v, v_off, s[base]` form, no 64-bit vector address arithmetic in the loop.
+    const unsigned int lane_bytes = (unsigned int)(L.off + iy_lo) * 8u;     // multiple of 16 (off + iy_lo is even)
+    auto pair = [&](const double* __restrict__ rowp, double& s0, double& s1) {
+        const double2 v = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(rowp) + lane_bytes);
+        s0 = D > 0 ? v.x : v.y; s1 = D > 0 ? v.y : v.x;
+    };
+    auto load = [&](int n, Row2& r) {
+        const int ix = D > 0 ? n : L.Nx + 1 - n;
+        const long long rb = (long long)ix * L.pitch;       // wave-uniform
+        pair(q0p + rb, r.rho[0], r.rho[1]); pair(q1p + rb, r.jx[0], r.jx[1]); pair(q2p + rb, r.jy[0], r.jy[1]);
+        if (TOPO == 0) {
+            pair(hp + rb, r.h[0], r.h[1]); pair(hxp + rb, r.hx[0], r.hx[1]); pair(hyp + rb, r.hy[0], r.hy[1]);
+        } else if (TOPO == 1) {
+            const double th = a.topo_line[ix], thx = a.topo_line[(L.Nx + 2) + ix], thy = a.topo_line[2 * (L.Nx + 2) + ix];
+            r.h[0] = r.h[1] = th; r.hx[0] = r.hx[1] = thx; r.hy[0] = r.hy[1] = thy;
+        } else {
+            r.h[0] = lh[0]; r.h[1] = lh[1]; r.hx[0] = lhx[0]; r.hx[1] = lhx[1]; r.hy[0] = lhy[0]; r.hy[1] = lhy[1];
+        }
+        if (HAS_LS) pair(a.Ls + rb, r.Ls[0], r.Ls[1]);
+        else r.Ls[0] = r.Ls[1] = 0.0;
+    };
+    auto cell_of = [&](const Row2& r, int k) {
+        CellIn c;
+        c.rho = r.rho[k]; c.jx = r.jx[k]; c.jy = r.jy[k]; c.h = r.h[k]; c.hx = r.hx[k]; c.hy = r.hy[k]; c.Ls = r.Ls[k];
+        return c;
+    };
+
+    Red<EOS> red;
+    red.init();
+    const int seam_row_lo = a.E.halo[0] == 2 ? 1 : -1, seam_row_hi = a.E.halo[1] == 2 ? L.Nx : -1;
+
+    // ---- fused: stage-1 field on a periodic downwind ghost row = the predictor's result on the partner row, logical
+    //      row 1, from the stored rows 0 and 1 (problem.py:560, 682-695) ----
+    if (fused && dw_row_is_ghost && x_periodic) {
+        Row2 r0, r1;
+        load(0, r0);
+        load(1, r1);
+        double fy[2][3], q1[2][3];
+        CellFlux f0[2], f1[2];
+        for (int k = 0; k < 2; ++k) {
+            cell_closure<EOS, false, HAS_LS, PIEZO>(cell_of(r0, k), P, f0[k]);
+            cell_closure<EOS, true, HAS_LS, PIEZO>(cell_of(r1, k), P, f1[k]);
+            fy[k][0] = r1.jy[k]; fy[k][1] = f1[k].fx2; fy[k][2] = f1[k].fy2;
+        }
+        const double u0 = lane_from_below(fy[1][0]), u1 = lane_from_below(fy[1][1]), u2 = lane_from_below(fy[1][2]);
+        const double up[2][3] = {{u0, u1, u2}, {fy[0][0], fy[0][1], fy[0][2]}};
+        for (int k = 0; k < 2; ++k) {
+            q1[k][0] = r1.rho[k] - dt * (cx * (r1.jx[k] - r0.jx[k]) + cy * (fy[k][0] - up[k][0]) - f1[k].s0);
+            q1[k][1] = r1.jx[k] - dt * (cx * (f1[k].fx1 - f0[k].fx1) + cy * (fy[k][1] - up[k][1]) - f1[k].s1);
+            q1[k][2] = r1.jy[k] - dt * (cx * (f1[k].fx2 - f0[k].fx2) + cy * (fy[k][2] - up[k][2]) - f1[k].s2);
+            for (int c = 0; c < 3; ++c) stash[c][2 * lane + k] = q1[k][c];
+        }
+    }
+
+    // rows n+1 (and n+2) are in flight while row n is computed
+    Row2 cur, nxt;
+#if GPF_K2_DEPTH == 2
+    Row2 nxt2;
+#endif
+    load(n_first - 1, cur);
+    load(n_first, nxt);
+
+    // carried from the previous row, per slot
+    double fx1p[2][3] = {{0, 0, 0}, {0, 0, 0}};     // stage-1 x-flux of row n-1
+    double part[2][3] = {{0, 0, 0}, {0, 0, 0}};     // row n-1: q(t0) + q1 - dt*(-cx*Fx2 + cy*dFy2 - S2)
+
+    for (int n = n_first - 1; n <= n_last + 1; ++n) {
+#if GPF_K2_DEPTH == 2
+        if (n < n_last) load(n + 2, nxt2);
+#endif
+        const bool first = (n == n_first - 1);
+        const bool last = (n == n_last + 1);
+        const int ix = D > 0 ? n : L.Nx + 1 - n;
+
+        TopoRcp tr[2];
+        tr[0] = topo_rcp<HAS_LS>(cell_of(cur, 0));
+        tr[1] = topo_rcp<HAS_LS>(cell_of(cur, 1));
+
+        // ---- stage 1 at (n, m) ----
+        double q1[2][3];
+        if (last && dw_row_is_ghost) {
+            if (fused) {
+                for (int k = 0; k < 2; ++k)
+                    for (int c = 0; c < 3; ++c) q1[k][c] = stash[c][2 * lane + k];
+            } else {
+                const int c0 = min(max(iy0, 0), L.Ny + 1), c1 = min(max(iy1, 0), L.Ny + 1);
+                for (int c = 0; c < 3; ++c) {
+                    q1[0][c] = a.g1x[c * L.pitch + L.off + c0];
+                    q1[1][c] = a.g1x[c * L.pitch + L.off + c1];
+                }
+            }
+        } else {
+            CellFlux f[2];
+            double fy[2][3];
+            for (int k = 0; k < 2; ++k) {
+                cell_closure<EOS, true, HAS_LS, PIEZO>(cell_of(cur, k), tr[k], P, f[k]);
+                fy[k][0] = cur.jy[k]; fy[k][1] = f[k].fx2; fy[k][2] = f[k].fy2;
+            }
+            const double u0 = lane_from_below(fy[1][0]), u1 = lane_from_below(fy[1][1]), u2 = lane_from_below(fy[1][2]);
+            const double up[2][3] = {{u0, u1, u2}, {fy[0][0], fy[0][1], fy[0][2]}};
+            for (int k = 0; k < 2; ++k) {
+                q1[k][0] = cur.rho[k] - dt * (cx * (cur.jx[k] - fx1p[k][0]) + cy * (fy[k][0] - up[k][0]) - f[k].s0);
+                q1[k][1] = cur.jx[k] - dt * (cx * (f[k].fx1 - fx1p[k][1]) + cy * (fy[k][1] - up[k][1]) - f[k].s1);
+                q1[k][2] = cur.jy[k] - dt * (cx * (f[k].fx2 - fx1p[k][2]) + cy * (fy[k][2] - up[k][2]) - f[k].s2);
+                fx1p[k][0] = cur.jx[k]; fx1p[k][1] = f[k].fx1; fx1p[k][2] = f[k].fx2;
+            }
+            if (ghost_strip) {
+                // stage-1 field on the downwind ghost COLUMN (logical column Ny+1): the ghost rule applied to the
+                // predictor's result on its source column (problem.py:560) -- logical column 1 (periodic: computed by
+                // the wrap lanes of this wave) or logical column Ny (the slot just upwind of the ghost slot)
+                double gv[3];
+                if (!fused) {
+                    for (int c = 0; c < 3; ++c) gv[c] = a.g1y[c * (L.Nx + 2) + ix];
+                } else {
+                    for (int c = 0; c < 3; ++c)
+                        gv[c] = ghost_rule(a.E, e_dw_y, c, __shfl(gsrc_slot ? q1[1][c] : q1[0][c], gsrc_lane));
+                }
+                if (is_ghost_lane) {
+                    for (int c = 0; c < 3; ++c) {
+                        if (G.slot_ghost) q1[1][c] = gv[c];
+                        else q1[0][c] = gv[c];
+                    }
+                }
+            }
+            // fused, Dirichlet / Neumann in x: the ghost rule applied to the last interior row's predictor result
+            if (fused && n == n_last && dw_row_is_ghost && !x_periodic) {
+                for (int k = 0; k < 2; ++k)
+                    for (int c = 0; c < 3; ++c) stash[c][2 * lane + k] = ghost_rule(a.E, e_dw_x, c, q1[k][c]);
+            }
+        }
+
+        if (!first) {
+            // ---- stage 2 closure at (n, m) on the stage-1 field ----
+            CellFlux g[2];
+            double gy[2][3];
+            for (int k = 0; k < 2; ++k) {
+                CellIn c1 = cell_of(cur, k);
+                c1.rho = q1[k][0]; c1.jx = q1[k][1]; c1.jy = q1[k][2];
+                cell_closure<EOS, true, HAS_LS, PIEZO>(c1, tr[k], P, g[k]);
+                gy[k][0] = q1[k][2]; gy[k][1] = g[k].fx2; gy[k][2] = g[k].fy2;
+            }
+            const double d0 = lane_from_above(gy[0][0]), d1 = lane_from_above(gy[0][1]), d2 = lane_from_above(gy[0][2]);
+            const double dn[2][3] = {{gy[1][0], gy[1][1], gy[1][2]}, {d0, d1, d2}};
+
+            // ---- finish row n-1: corrector + time average (problem.py:558, 563) ----
+            if (n > n_first) {
+                double o[2][3];
+                for (int k = 0; k < 2; ++k) {
+                    o[k][0] = 0.5 * (part[k][0] - dt * cx * q1[k][1]);
+                    o[k][1] = 0.5 * (part[k][1] - dt * cx * g[k].fx1);
+                    o[k][2] = 0.5 * (part[k][2] - dt * cx * g[k].fx2);
+                }
+                const int ixo = D > 0 ? n - 1 : L.Nx + 2 - n;
+                const long long rbo = (long long)ixo * L.pitch;     // wave-uniform
+                auto st16 = [&](double* __restrict__ rowp, double va, double vb) {
+                    *reinterpret_cast<double2*>(reinterpret_cast<char*>(rowp) + lane_bytes) = D > 0 ? make_double2(va, vb) : make_double2(vb, va);
+                };
+                auto st8 = [&](double* __restrict__ rowp, unsigned int bytes, double v) {
+                    *reinterpret_cast<double*>(reinterpret_cast<char*>(rowp) + bytes) = v;
+                };
+                if (out0 && out1) {
+                    st16(qo0 + rbo, o[0][0], o[1][0]); st16(qo1 + rbo, o[0][1], o[1][1]); st16(qo2 + rbo, o[0][2], o[1][2]);
+                } else if (out0) {
+                    const unsigned int b = (unsigned int)(L.off + iy0) * 8u;
+                    st8(qo0 + rbo, b, o[0][0]); st8(qo1 + rbo, b, o[0][1]); st8(qo2 + rbo, b, o[0][2]);
+                } else if (out1) {
+                    const unsigned int b = (unsigned int)(L.off + iy1) * 8u;
+                    st8(qo0 + rbo, b, o[1][0]); st8(qo1 + rbo, b, o[1][1]); st8(qo2 + rbo, b, o[1][2]);
+                }
+                // a row next to a periodic slab seam also stands in for the far slab's ghost row
+                const double w = 1.0 + (ixo == seam_row_lo ? 1.0 : 0.0) + (ixo == seam_row_hi ? 1.0 : 0.0);
+                if (out0) red.cell(o[0][0], o[0][1], o[0][2], w, P);
+                if (out1) red.cell(o[1][0], o[1][1], o[1][2], w, P);
+            }
+            // ---- open row n (an output row unless this is the downwind extra row) ----
+            for (int k = 0; k < 2; ++k) {
+                part[k][0] = (cur.rho[k] + q1[k][0]) - dt * (-cx * q1[k][1] + cy * (dn[k][0] - gy[k][0]) - g[k].s0);
+                part[k][1] = (cur.jx[k] + q1[k][1]) - dt * (-cx * g[k].fx1 + cy * (dn[k][1] - gy[k][1]) - g[k].s1);
+                part[k][2] = (cur.jy[k] + q1[k][2]) - dt * (-cx * g[k].fx2 + cy * (dn[k][2] - gy[k][2]) - g[k].s2);
+            }
+        }
+        cur = nxt;
+#if GPF_K2_DEPTH == 2
+        nxt = nxt2;
+#else
+        if (n <= n_last) load(n + 2, nxt);
+#endif
+    }
+
+    // ---- fused: ghost cells of the field this step has produced (problem.py:576 -> 676-768) ----
+    // Outside the march: the wave re-reads its OWN finished cells next to an edge (its stores are drained first; a CU's
+    // L1 is coherent with its own stores), applies the ghost rule and writes the ghost cells; they enter the
+    // reductions like every cell (problem.py:342-347).  x edge e: ghost row ix = e ? Nx+1 : 0; its source row is the
+    // partner row (periodic) or the adjacent one; y edges alike; corners are rule_y(rule_x(.)) as the reference's
+    // x-then-y order produces them.
+    if (fused) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int src_row[2] = {x_periodic ? L.Nx : 1, x_periodic ? 1 : L.Nx};
+        const int src_col[2] = {y_periodic ? L.Ny : 1, y_periodic ? 1 : L.Ny};      // y edge 2 (iy = 0), 3 (iy = Ny+1)
+        const int ix_lo = D > 0 ? n_first : L.Nx + 1 - n_last, ix_hi = D > 0 ? n_last : L.Nx + 1 - n_first;
+        auto get = [&](int ix, int iy, double v[3]) {
+            const long long o = (long long)ix * L.pitch + L.off + iy;
+            v[0] = qo0[o]; v[1] = qo1[o]; v[2] = qo2[o];
+        };
+        auto put = [&](int ix, int iy, const double v[3]) {
+            const long long o = (long long)ix * L.pitch + L.off + iy;
+            qo0[o] = v[0]; qo1[o] = v[1]; qo2[o] = v[2];
+            red.cell(v[0], v[1], v[2], 1.0, P);
+        };
+        // ghost columns: one lane per row of the chunk
+        const int m_out_lo = max(G.w0 + strip * STRIP2 + 1, 1), m_out_hi = min(G.w0 + strip * STRIP2 + STRIP2, L.Ny);
+        for (int ey = 0; ey < 2; ++ey) {
+            const int msrc = D > 0 ? src_col[ey] : L.Ny + 1 - src_col[ey];
+            if (msrc < m_out_lo || msrc > m_out_hi) continue;                       // wave-uniform: not this strip's column
+            for (int ix = ix_lo + lane; ix <= ix_hi; ix += 64) {
+                double v[3], g[3];
+                get(ix, src_col[ey], v);
+                for (int c = 0; c < 3; ++c) g[c] = ghost_rule(a.E, 2 + ey, c, v[c]);
+                put(ix, ey ? L.Ny + 1 : 0, g);
+            }
+        }
+        // ghost rows (and corners): the lanes re-read the source row at their own output columns
+        for (int e = 0; e < 2; ++e) {
+            if (src_row[e] < ix_lo || src_row[e] > ix_hi) continue;                 // wave-uniform: not this chunk's row
+            const int ixg = e ? L.Nx + 1 : 0;
+            for (int k = 0; k < 2; ++k) {
+                if (!(k ? out1 : out0)) continue;
+                const int iy = k ? iy1 : iy0;
+                double v[3], g[3], gc[3];
+                get(src_row[e], iy, v);
+                for (int c = 0; c < 3; ++c) g[c] = ghost_rule(a.E, e, c, v[c]);
+                put(ixg, iy, g);
+                for (int ey = 0; ey < 2; ++ey) {
+                    if (iy != src_col[ey]) continue;
+                    for (int c = 0; c < 3; ++c) gc[c] = ghost_rule(a.E, 2 + ey, c, g[c]);
+                    put(ixg, ey ? L.Ny + 1 : 0, gc);
+                }
+            }
+        }
+    }
+
+    // ---- wave reduction: the record is valid in lane 0 ----
+    for (int s = 32; s >= 1; s >>= 1) {
+        red.ekin += __shfl_down(red.ekin, s);
+        red.v2 = fmax(red.v2, __shfl_down(red.v2, s));
+        const double oc = __shfl_down(red.c2, s);
+        red.c2 = (EOS == EOS_DH) ? fmin(red.c2, oc) : fmax(red.c2, oc);
+        red.flags |= __shfl_down(red.flags, s);
+    }
+    if (EOS == EOS_DH) {                    // same expression as eos_c2<EOS_DH> at the cell nearest the pole
+        const double it = rcp(red.c2);
+        red.c2 = (red.c2 == __builtin_inf()) ? 0.0 : P.e[6] * (it * it);
+    }
+    result.ekin = red.ekin; result.v2 = red.v2; result.c2 = red.c2; result.mass = 0.0; result.flags = red.flags;
+}
+
+// D = direction of the predictor, chosen by the host from the step index (problem.py:521-522) and checked against the
+// device-side step counter.  Grid: gridDim.x = a multiple of 8 blocks of 4 waves; wave w of the XCD-ordered numbering
+// works on strip w % nstrips of chunk w / nstrips.
+template <int EOS, bool HAS_LS, bool PIEZO, int D, int TOPO>
+__global__ __launch_bounds__(256, GPF_K2_MINWAVES) void k_step2(const Step2Args a, const Phys P) {
+    __shared__ double stash[4][3][128];         // per wave: stage-1 field on the downwind ghost row (fused)
+    __shared__ Acc red_sm[4];
+    __shared__ int s_last;
+    if (halted(a.st, a.honor_stop)) return;
+    if (predictor_direction(a.st) != D) __builtin_trap();
+    const int par = a.st->parity;
+    const double* qin = par ? a.qb : a.qa;
+    double* qout = const_cast<double*>(par ? a.qa : a.qb);
+
+    // blocks b and b + 8 share an XCD (round-robin dispatch): give each XCD a contiguous range of waves, so that
+    // neighbouring strips -- which share their halo columns' cache lines -- meet in the same L2
+    const int nb = gridDim.x;
+    const int lb = (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3);
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = lb * 4 + wv;
+    const int strip = w % a.G.nstrips, chunk = w / a.G.nstrips;
+    const bool active = chunk < a.nchunks;      // wave-uniform
+
+    Acc own;
+    own.zero();
+    if (active) step_strip2<EOS, HAS_LS, PIEZO, D, TOPO>(a, P, qin, qout, strip, chunk, lane, stash[wv], own);
+
+    if (!a.fused) {
+        if (active && lane == 0) {
+            Partial p;
+            p.ekin = own.ekin; p.vmax2 = own.v2; p.c2max = own.c2; p.flags = (double)own.flags;
+            a.partials[w] = p;
+        }
+        return;
+    }
+    // ---- fused: one record per block; the last block to arrive folds them and commits the step ----
+    if (lane == 0) red_sm[wv] = own;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Acc tot = red_sm[0];
+        for (int i = 1; i < 4; ++i) { tot.ekin += red_sm[i].ekin; tot.v2 = fmax(tot.v2, red_sm[i].v2); tot.c2 = fmax(tot.c2, red_sm[i].c2); tot.flags |= red_sm[i].flags; }
+        publish_partial(a.block_partials + blockIdx.x, tot);       // write-through + drained: see aux_kernels.hip
+        const unsigned int t = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == (unsigned int)nb - 1) ? 1 : 0;
+        if (s_last) __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    Acc acc;
+    acc.zero();
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) merge_published(acc, a.block_partials + i);
+    acc = block_reduce(acc, red_sm);
+    if (threadIdx.x == 0) commit_step(a.st, acc.ekin, acc.v2, acc.c2, acc.flags, a.log, a.log_base, a.log_cap);
+}
+
+}  // namespace gpf
