@@ -28,23 +28,33 @@ def is_stale():
     return any(os.path.exists(os.path.join(CSRC, d)) and os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
-def build_library(force=False, verbose=False):
-    """Compile csrc/*.hip into lib/libgapflow_hip.so; returns the library path."""
-    if not force and not is_stale():
+def build_library(force=False, verbose=False, out=None, extra_flags=()):
+    """Compile csrc/*.hip into lib/libgapflow_hip.so; returns the library path.
+
+    `out` / `extra_flags` build an A/B variant next to it (lib/variants/<name>.so, selected at run time with
+    GPF_LIB_PATH); the default library is rebuilt only when a source is newer (or with force=True)."""
+    lib = out or LIB
+    if out is None and not force and not is_stale():
+        if verbose:
+            print('up to date, reused', LIB)
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    extra = os.environ.get('GPF_EXTRA_FLAGS', '').split()        # diagnostics, e.g. -DGPF_STUB_CLOSURE
-    cmd = [HIPCC] + FLAGS + extra + ['-Rpass-analysis=kernel-resource-usage', '-o', LIB] + SOURCES + LIBS
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
+    extra = os.environ.get('GPF_EXTRA_FLAGS', '').split() + list(extra_flags)       # diagnostics, e.g. -DGPF_STUB_CLOSURE
+    cmd = [HIPCC] + FLAGS + extra + ['-Rpass-analysis=kernel-resource-usage', '-o', lib] + SOURCES + LIBS
     res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
-    with open(os.path.join(LIBDIR, 'resource_usage.txt'), 'w') as f:
+    with open(os.path.splitext(lib)[0] + '.resource_usage.txt' if out else os.path.join(LIBDIR, 'resource_usage.txt'), 'w') as f:
         f.write(res.stderr)
     if res.returncode != 0:
         errs = [ln for ln in res.stderr.splitlines() if 'remark:' not in ln]
         raise RuntimeError('hipcc failed:\n' + '\n'.join(errs[-60:]))
     if verbose:
-        print('built', LIB)
-    return LIB
+        print('compiled', lib)
+    return lib
 
 
 if __name__ == '__main__':
-    build_library(force='--force' in sys.argv, verbose=True)
+    if '--variant' in sys.argv:         # python -m gapflow_amd.build --variant NAME [flags...]
+        i = sys.argv.index('--variant')
+        build_library(out=os.path.join(LIBDIR, 'variants', sys.argv[i + 1] + '.so'), extra_flags=sys.argv[i + 2:], verbose=True)
+    else:
+        build_library(force='--force' in sys.argv, verbose=True)

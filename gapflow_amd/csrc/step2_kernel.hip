@@ -30,11 +30,14 @@
 namespace gpf {
 
 constexpr int STRIP2 = 126;     // output columns per wavefront
-#ifndef GPF_K2_DEPTH
-#define GPF_K2_DEPTH 2          // rows in flight ahead of the one being computed
+#ifndef GPF_K2_AHEAD
+#define GPF_K2_AHEAD 2          // rows requested ahead of the one being computed (1 or 2)
 #endif
 #ifndef GPF_K2_MINWAVES
 #define GPF_K2_MINWAVES 2       // waves per SIMD the register allocation is held to
+#endif
+#ifndef GPF_K2_MINWAVES_LINE
+#define GPF_K2_MINWAVES_LINE GPF_K2_MINWAVES    // ... for the x-only-gap kernels (half the row buffers)
 #endif
 
 // Where the windows sit, per predictor direction (host: strip2_geom in api.hip).
@@ -88,6 +91,44 @@ __device__ __forceinline__ double lane_from_above(double v) {          // lane l
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 #endif
 }
+
+// The row loads of the march are issued through inline asm so that THIS file, not the compiler, decides when a
+// wave waits for them.  hipcc's own s_waitcnt placement is exact in straight-line code but gives up at the loop back
+// edge and at the exec-masked store branches: it drained every outstanding load (vmcnt(0)) once per row, which put
+// the full HBM latency of the row just requested in front of every row's arithmetic.  vmcnt counts loads and stores
+// together in issue order, so "at most N younger operations outstanding" needs only a LOWER bound N on the number of
+// vector-memory instructions issued after the loads being waited for: the loads of the rows requested since (the
+// compiler's stores in between only make the wait stricter, never unsafe).  Form (ii) of the CDNA4 guide, section 5.7:
+// "=v" loads, then one wait statement naming every destination "+v" before the first consumer.
+typedef double dpair __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void asm_load16(dpair& dst, const double* lane_ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(lane_ptr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void asm_wait3(dpair& a, dpair& b, dpair& c) {
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void asm_wait1(dpair& a) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
+}
+
+// A wave-uniform load of data this kernel never writes (the topography profile, the slabs' stage-1 ghost column):
+// through the constant address space, i.e. the scalar cache (s_load, counted by lgkmcnt).  As a plain load hipcc
+// issues it as a vector load, and its vmcnt bookkeeping for that load -- blind to the asm row loads -- drains them.
+__device__ __forceinline__ double uniform_load(const double* p) {
+    typedef const __attribute__((address_space(4))) double* cptr;
+    return *(cptr)(unsigned long long)p;
+}
+
+// one row as loaded: .x is the lower physical column of the lane's pair
+template <int TOPO, bool HAS_LS>
+struct RawRow {
+    dpair q[3];
+    dpair t[TOPO == 0 ? 3 : 1];     // h, hx, hy planes (TOPO = 0 only)
+    dpair ls[HAS_LS ? 1 : 1];
+    double th, thx, thy;            // TOPO = 1: the row's (h, hx, hy), wave-uniform
+};
 
 // two adjacent cells of one row, as one lane holds them
 struct Row2 { double rho[2], jx[2], jy[2], h[2], hx[2], hy[2], Ls[2]; };
@@ -193,6 +234,45 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
         if (HAS_LS) pair(a.Ls + rb, r.Ls[0], r.Ls[1]);
         else r.Ls[0] = r.Ls[1] = 0.0;
     };
+    // ---- the pipelined row loads of the march ----
+    constexpr int NL = 3 + (TOPO == 0 ? 3 : 0) + (HAS_LS ? 1 : 0);       // vector loads per row
+    typedef RawRow<TOPO, HAS_LS> Raw;
+    const double* const lane_q = reinterpret_cast<const double*>(reinterpret_cast<const char*>(qin) + lane_bytes);
+    const double* const lane_t = reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.topo) + lane_bytes);
+    const double* const lane_ls = HAS_LS ? reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.Ls) + lane_bytes) : nullptr;
+    auto issue = [&](int n, Raw& r) {
+        const int ix = D > 0 ? n : L.Nx + 1 - n;
+        const long long rb = (long long)ix * L.pitch;       // wave-uniform
+        asm_load16(r.q[0], lane_q + rb); asm_load16(r.q[1], lane_q + L.plane + rb); asm_load16(r.q[2], lane_q + 2 * L.plane + rb);
+        if (TOPO == 0) {
+            asm_load16(r.t[0], lane_t + rb); asm_load16(r.t[1], lane_t + L.plane + rb); asm_load16(r.t[2], lane_t + 2 * L.plane + rb);
+        } else if (TOPO == 1) {
+            r.th = uniform_load(a.topo_line + ix); r.thx = uniform_load(a.topo_line + (L.Nx + 2) + ix); r.thy = uniform_load(a.topo_line + 2 * (L.Nx + 2) + ix);
+        }
+        if (HAS_LS) asm_load16(r.ls[0], lane_ls + rb);
+    };
+    // wait until row r has landed: exactly GPF_K2_AHEAD row requests (NL loads each) have been issued after it
+    auto arrive = [&](Raw& r) {
+        asm_wait3<GPF_K2_AHEAD * NL>(r.q[0], r.q[1], r.q[2]);
+        if (TOPO == 0) asm_wait3<GPF_K2_AHEAD * NL>(r.t[0], r.t[1], r.t[2]);
+        if (HAS_LS) asm_wait1<GPF_K2_AHEAD * NL>(r.ls[0]);
+    };
+    auto unpack = [&](const Raw& r, Row2& o) {
+        o.rho[0] = D > 0 ? r.q[0].x : r.q[0].y; o.rho[1] = D > 0 ? r.q[0].y : r.q[0].x;
+        o.jx[0] = D > 0 ? r.q[1].x : r.q[1].y; o.jx[1] = D > 0 ? r.q[1].y : r.q[1].x;
+        o.jy[0] = D > 0 ? r.q[2].x : r.q[2].y; o.jy[1] = D > 0 ? r.q[2].y : r.q[2].x;
+        if (TOPO == 0) {
+            o.h[0] = D > 0 ? r.t[0].x : r.t[0].y; o.h[1] = D > 0 ? r.t[0].y : r.t[0].x;
+            o.hx[0] = D > 0 ? r.t[1].x : r.t[1].y; o.hx[1] = D > 0 ? r.t[1].y : r.t[1].x;
+            o.hy[0] = D > 0 ? r.t[2].x : r.t[2].y; o.hy[1] = D > 0 ? r.t[2].y : r.t[2].x;
+        } else if (TOPO == 1) {
+            o.h[0] = o.h[1] = r.th; o.hx[0] = o.hx[1] = r.thx; o.hy[0] = o.hy[1] = r.thy;
+        } else {
+            o.h[0] = lh[0]; o.h[1] = lh[1]; o.hx[0] = lhx[0]; o.hx[1] = lhx[1]; o.hy[0] = lhy[0]; o.hy[1] = lhy[1];
+        }
+        if (HAS_LS) { o.Ls[0] = D > 0 ? r.ls[0].x : r.ls[0].y; o.Ls[1] = D > 0 ? r.ls[0].y : r.ls[0].x; }
+        else o.Ls[0] = o.Ls[1] = 0.0;
+    };
     auto cell_of = [&](const Row2& r, int k) {
         CellIn c;
         c.rho = r.rho[k]; c.jx = r.jx[k]; c.jy = r.jy[k]; c.h = r.h[k]; c.hx = r.hx[k]; c.hy = r.hy[k]; c.Ls = r.Ls[k];
@@ -226,22 +306,38 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
         }
     }
 
-    // rows n+1 (and n+2) are in flight while row n is computed
-    Row2 cur, nxt;
-#if GPF_K2_DEPTH == 2
-    Row2 nxt2;
-#endif
-    load(n_first - 1, cur);
-    load(n_first, nxt);
+    // slabs: the stage-1 field on the downwind ghost row was prepared by k_ghost_stage1 / k_begin_slab.  It is staged
+    // here, outside the march: a compiler-visible vector load inside the loop would make hipcc drain the pipelined
+    // row loads (its wait counts cannot see them).
+    if (!fused && dw_row_is_ghost) {
+        const int c0 = min(max(iy0, 0), L.Ny + 1), c1 = min(max(iy1, 0), L.Ny + 1);
+        for (int c = 0; c < 3; ++c) {
+            stash[c][2 * lane] = a.g1x[c * L.pitch + L.off + c0];
+            stash[c][2 * lane + 1] = a.g1x[c * L.pitch + L.off + c1];
+        }
+    }
+
+    // Rows n+1 .. n+AHEAD are in flight while row n is computed: at the top of row n the request for row n+AHEAD goes
+    // out, then the wave waits for row n alone (requested AHEAD rows ago; a row of arithmetic lasts longer than an
+    // HBM round trip).  AHEAD + 1 row buffers rotate by NAME: the loop body is a lambda instantiated once per
+    // buffer, so no register copies are needed to advance the window.
+    constexpr int AHEAD = GPF_K2_AHEAD;
+    Raw rowbuf[AHEAD + 1];
+    issue(n_first - 1, rowbuf[0]);
+    if (AHEAD == 2) issue(n_first, rowbuf[1]);
 
     // carried from the previous row, per slot
     double fx1p[2][3] = {{0, 0, 0}, {0, 0, 0}};     // stage-1 x-flux of row n-1
     double part[2][3] = {{0, 0, 0}, {0, 0, 0}};     // row n-1: q(t0) + q1 - dt*(-cx*Fx2 + cy*dFy2 - S2)
 
-    for (int n = n_first - 1; n <= n_last + 1; ++n) {
-#if GPF_K2_DEPTH == 2
-        if (n < n_last) load(n + 2, nxt2);
-#endif
+    // one row of the march: `raw` holds (or is about to hold) row n, `spare` is the buffer row n-1 has vacated
+    auto march = [&](const int n, Raw& raw, Raw& spare) {
+        // Beyond the chunk's last row the request repeats that row (an L2 hit, never used): the number of loads in
+        // flight behind `raw` is then the same in every iteration, and the wait needs no case distinction.
+        issue(min(n + AHEAD, n_last + 1), spare);
+        arrive(raw);
+        Row2 cur;
+        unpack(raw, cur);
         const bool first = (n == n_first - 1);
         const bool last = (n == n_last + 1);
         const int ix = D > 0 ? n : L.Nx + 1 - n;
@@ -253,16 +349,8 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
         // ---- stage 1 at (n, m) ----
         double q1[2][3];
         if (last && dw_row_is_ghost) {
-            if (fused) {
-                for (int k = 0; k < 2; ++k)
-                    for (int c = 0; c < 3; ++c) q1[k][c] = stash[c][2 * lane + k];
-            } else {
-                const int c0 = min(max(iy0, 0), L.Ny + 1), c1 = min(max(iy1, 0), L.Ny + 1);
-                for (int c = 0; c < 3; ++c) {
-                    q1[0][c] = a.g1x[c * L.pitch + L.off + c0];
-                    q1[1][c] = a.g1x[c * L.pitch + L.off + c1];
-                }
-            }
+            for (int k = 0; k < 2; ++k)
+                for (int c = 0; c < 3; ++c) q1[k][c] = stash[c][2 * lane + k];
         } else {
             CellFlux f[2];
             double fy[2][3];
@@ -284,7 +372,7 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
                 // the wrap lanes of this wave) or logical column Ny (the slot just upwind of the ghost slot)
                 double gv[3];
                 if (!fused) {
-                    for (int c = 0; c < 3; ++c) gv[c] = a.g1y[c * (L.Nx + 2) + ix];
+                    for (int c = 0; c < 3; ++c) gv[c] = uniform_load(a.g1y + c * (L.Nx + 2) + ix);
                 } else {
                     for (int c = 0; c < 3; ++c)
                         gv[c] = ghost_rule(a.E, e_dw_y, c, __shfl(gsrc_slot ? q1[1][c] : q1[0][c], gsrc_lane));
@@ -353,12 +441,18 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
                 part[k][2] = (cur.jy[k] + q1[k][2]) - dt * (-cx * g[k].fx2 + cy * (dn[k][2] - gy[k][2]) - g[k].s2);
             }
         }
-        cur = nxt;
-#if GPF_K2_DEPTH == 2
-        nxt = nxt2;
-#else
-        if (n <= n_last) load(n + 2, nxt);
-#endif
+    };
+    for (int n = n_first - 1;;) {
+        march(n, rowbuf[0], rowbuf[AHEAD]); if (++n > n_last + 1) break;
+        march(n, rowbuf[1], rowbuf[0]); if (++n > n_last + 1) break;
+        if (AHEAD == 2) { march(n, rowbuf[2 % (AHEAD + 1)], rowbuf[1]); if (++n > n_last + 1) break; }
+    }
+    // The last requests (repeats of the final row) are still in flight: drain them while the buffers are still
+    // live, or a late return would land in registers the code below has reused.
+    for (int b = 0; b <= AHEAD; ++b) {
+        asm_wait3<0>(rowbuf[b].q[0], rowbuf[b].q[1], rowbuf[b].q[2]);
+        if (TOPO == 0) asm_wait3<0>(rowbuf[b].t[0], rowbuf[b].t[1], rowbuf[b].t[2]);
+        if (HAS_LS) asm_wait1<0>(rowbuf[b].ls[0]);
     }
 
     // ---- fused: ghost cells of the field this step has produced (problem.py:576 -> 676-768) ----
@@ -432,7 +526,7 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
 // device-side step counter.  Grid: gridDim.x = a multiple of 8 blocks of 4 waves; wave w of the XCD-ordered numbering
 // works on strip w % nstrips of chunk w / nstrips.
 template <int EOS, bool HAS_LS, bool PIEZO, int D, int TOPO>
-__global__ __launch_bounds__(256, GPF_K2_MINWAVES) void k_step2(const Step2Args a, const Phys P) {
+__global__ __launch_bounds__(256, (TOPO == 1 ? GPF_K2_MINWAVES_LINE : GPF_K2_MINWAVES)) void k_step2(const Step2Args a, const Phys P) {
     __shared__ double stash[4][3][128];         // per wave: stage-1 field on the downwind ghost row (fused)
     __shared__ Acc red_sm[4];
     __shared__ int s_last;
@@ -446,7 +540,9 @@ __global__ __launch_bounds__(256, GPF_K2_MINWAVES) void k_step2(const Step2Args 
     // neighbouring strips -- which share their halo columns' cache lines -- meet in the same L2
     const int nb = gridDim.x;
     const int lb = (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3);
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index is wave-uniform, but only readfirstlane tells the compiler: strip, chunk, the row loop, its
+    // branches and the row base addresses then live in scalar registers
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int w = lb * 4 + wv;
     const int strip = w % a.G.nstrips, chunk = w / a.G.nstrips;
     const bool active = chunk < a.nchunks;      // wave-uniform

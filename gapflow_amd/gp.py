@@ -265,11 +265,15 @@ class Database:
         if nsample <= 0:
             return
         print(f"Database contains less than {db['init_size']} MD runs.")
+        # `Xtest` is the (ncell, 7) feature table of all cells, or an object that serves its column means and rows on
+        # demand (slab.py: the whole domain's table is never built per rank)
+        lazy = hasattr(Xtest, 'column_mean')
+        mean = Xtest.column_mean if lazy else (lambda k: np.mean(Xtest[:, k]))
         if dim == 1:
-            flux, active = np.mean(Xtest[:, 1]), [0, 1]
+            flux, active = mean(1), [0, 1]
         else:
-            flux, active = np.hypot(np.mean(Xtest[:, 1]), np.mean(Xtest[:, 2])), [0, 1, 2]
-        rho, w = np.mean(Xtest[:, 0]), db['init_width']
+            flux, active = np.hypot(mean(1), mean(2)), [0, 1, 2]
+        rho, w = mean(0), db['init_width']
         lo = np.array([(1.0 - w) * rho, 0.5 * flux, -0.5 * flux])[active]
         hi = np.array([(1.0 + w) * rho, 1.5 * flux, 0.5 * flux])[active]
         rng = np.random.default_rng(db['init_seed'])
@@ -284,7 +288,8 @@ class Database:
         choice = rng.choice(Xtest.shape[0], size=nsample, replace=False)
         if len(active) == 2:
             samples = np.hstack([samples, np.zeros((nsample, 1))])
-        self.add_data(np.column_stack([samples, Xtest[choice, 3:]]))
+        picked = Xtest.rows(choice) if lazy else Xtest[choice]
+        self.add_data(np.column_stack([samples, picked[:, 3:]]))
 
     def add_data(self, Xnew):
         for X in np.atleast_2d(Xnew):

@@ -31,7 +31,7 @@ import numpy as np
 
 from . import _lib
 from .io import read_yaml_input
-from .topography import Topography
+from .topography import Topography, topography_rows
 
 HALO_PHYSICAL, HALO_NEIGHBOUR, HALO_SEAM = 0, 1, 2
 
@@ -192,6 +192,32 @@ class HipSlabEngine:
         _lib.check(self.lib.gpf_state(self.h, C.byref(sc)))     # synchronises; re-reads the device step counter
 
 
+class _DomainFeatures:
+    """The whole domain's (ncell, 7) feature table [rho, jx, jy, h, dh/dx, dh/dy, extra] of the initial state, rows on
+    demand: what Database.initialize asks of its `Xtest` (column means of the uniform initial field, the number of
+    cells, the features of a few hundred sampled cells) without a 3.8 GB table per rank at 8192^2."""
+
+    def __init__(self, q0, grid, topo_rows):
+        self._q0, self._topo_rows = np.asarray(q0, float), topo_rows
+        self._ny2 = grid['Ny'] + 2
+        self.shape = ((grid['Nx'] + 2) * self._ny2, 7)
+
+    def column_mean(self, k):
+        if k > 2:
+            raise NotImplementedError("only the (uniform) initial field has a mean here")
+        return float(self._q0[k])
+
+    def rows(self, cells):
+        cells = np.asarray(cells, int)
+        ix, iy = cells // self._ny2, cells % self._ny2
+        uniq, inv = np.unique(ix, return_inverse=True)
+        t = self._topo_rows(uniq)                           # (3, len(uniq), Ny+2)
+        out = np.zeros((len(cells), 7))
+        out[:, :3] = self._q0
+        out[:, 3:6] = t[:, inv, iy].T
+        return out
+
+
 class SlabProblem:
     """A Problem cut into x-slabs; construct it on every rank of an initialised process group."""
 
@@ -222,12 +248,18 @@ class SlabProblem:
         _lib.check(self.lib.gpf_create(C.byref(cfg), C.byref(self._h)))
         _lib.check(self.lib.gpf_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
-        # global topography on the host, sliced (profiles such as `asperity` need global cell means)
-        topo = Topography(grid, geo, prop).full
-        rows = L.rows()
+        # this slab's rows of the domain's topography (never the whole table: 2 GB per rank at 8192^2)
+        hmins = self._shared_asperity_heights(geo)
+        if geo.get('flip'):
+            whole = Topography(grid, geo, prop).full[:3]
+            topo_rows = lambda rows: whole[:, np.asarray(rows)]
+        else:
+            topo_rows = lambda rows: topography_rows(grid, geo, rows, hmins)
+        self._topo_rows = topo_rows
         shape = (L.nx + 2, grid['Ny'] + 2)
         self._shape = shape
-        self._upload(_lib.FIELD_TOPO, topo[:3, rows])
+        topo_local = topo_rows(np.arange(L.lo - 1, L.hi + 2))
+        self._upload(_lib.FIELD_TOPO, topo_local)
         q = np.empty((3,) + shape)
         q[0], q[1], q[2] = prop['rho0'], prop['rho0'] * geo['U'] / 2.0, prop['rho0'] * geo['V'] / 2.0
         self._upload(_lib.FIELD_Q, q)
@@ -235,7 +267,8 @@ class SlabProblem:
         for side, kind, (r_src, r_up) in ((0, L.kind_lo, (nxg, nxg + 1)), (1, L.kind_hi, (1, 0))):
             if kind == HALO_SEAM:
                 seam = np.zeros((2, 4, grid['Ny'] + 2))
-                seam[0, :3], seam[1, :3] = topo[:3, r_src], topo[:3, r_up]
+                two = topo_rows([r_src, r_up])
+                seam[0, :3], seam[1, :3] = two[:, 0], two[:, 1]
                 seam = _lib.f64c(seam)
                 _lib.check(self.lib.gpf_set_seam_topo(self._h, side, _lib.as_dp(seam), seam.size))
         self.engine = HipSlabEngine(self.lib, self._h, torch, self.world)
@@ -243,10 +276,9 @@ class SlabProblem:
 
         # surrogate closures: the database and the models are replicated on every rank
         self.grid, self._lib, self._closures_stale = grid, self.lib, True
-        self._topo_local = topo[:3, rows].copy()
+        self._topo_local = topo_local
         self._extra = np.zeros((1,) + shape)
-        self._features_global = np.vstack([np.broadcast_to(q[:, :1, :1], (3,) + topo.shape[1:]), topo[:3],
-                                           np.zeros((1,) + topo.shape[1:])]).reshape(7, -1).T
+        self._features_global = _DomainFeatures(q[:, 0, 0], grid, topo_rows)
         self.database, self._gp_models = None, {}
         gp = input_dict.get('gp')
         if input_dict.get('db') is not None:
@@ -263,6 +295,16 @@ class SlabProblem:
         if os.environ.get('GPF_SLAB_TRANSPORT', 'rccl') == 'p2p':
             if not self.connect_p2p():
                 raise RuntimeError("GPF_SLAB_TRANSPORT=p2p: the peers' mailboxes could not be mapped (HIP IPC)")
+
+    def _shared_asperity_heights(self, geo):
+        """topography.py:141-146 draws the minimum heights of num^2 asperities from an unseeded normal distribution: every
+        rank must use rank 0's draw."""
+        if geo['type'] != 'asperity' or geo['num'] == 1:
+            return None
+        h0, h1, num = geo['hmin'], geo['hmax'], geo['num']
+        box = [np.random.normal(loc=h0 + (h1 - h0) / 2., scale=(h1 - h0) / 2. / 2.57, size=num**2) if self.rank == 0 else None]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
 
     def connect_p2p(self):
         """Switch the fused slab step to the peer-to-peer transport (ranks of one node): exchange the mailboxes'

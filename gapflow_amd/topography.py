@@ -84,6 +84,44 @@ def asperity(xx, yy, grid, geo):
 _PROFILES_1D = {'journal': journal_bearing, 'inclined': inclined_slider, 'parabolic': parabolic_slider, 'cdc': cdc}
 
 
+def topography_rows(grid, geo, rows, hmins=None):
+    """h, dh/dx, dh/dy on rows `rows` (indices into the (Nx+2)-row array incl. ghost rows) of the WHOLE domain's
+    topography, shape (3, len(rows), Ny+2), without building the whole array: a slab of an 8192^2 problem needs 1026
+    rows, not a 2 GB table per rank.  The 1-D profiles are functions of x alone; an asperity's centre is the mean of the
+    cell centres it covers, which factorises into 1-D means (equal to the 2-D mean of `asperity` up to rounding).
+    `hmins` (num^2 minimum heights) must be given for num > 1 -- they are random draws every rank has to share."""
+    if geo.get('flip'):
+        raise NotImplementedError("row-wise topography of a flipped geometry")
+    rows = np.asarray(rows, int)
+    Lx, Ly, Nx, Ny = grid['Lx'], grid['Ly'], grid['Nx'], grid['Ny']
+    x_all = np.arange(-1, Nx + 1) / Nx * Lx + (Lx / Nx) / 2.
+    y = np.arange(-1, Ny + 1) / Ny * Ly + (Ly / Ny) / 2.
+    xx, yy = np.meshgrid(x_all[rows], y, indexing='ij')
+    if geo['type'] in _PROFILES_1D:
+        h, dh_dx, dh_dy = _PROFILES_1D[geo['type']](xx, grid, geo)
+    elif geo['type'] == 'asperity':
+        h0, h1, num = geo['hmin'], geo['hmax'], geo['num']
+        if hmins is None:
+            if num != 1:
+                raise ValueError("topography_rows: pass the shared minimum heights of the num^2 asperities")
+            hmins = np.array([h0])
+        xid_all, yid_all = (x_all // (Lx / num)).astype(int), (y // (Ly / num)).astype(int)
+        xid, yid = (xx // (Lx / num)).astype(int), (yy // (Ly / num)).astype(int)
+        bx, by = np.pi / (Lx / num), np.pi / (Ly / num)
+        h, dh_dx, dh_dy = np.full_like(xx, h1), np.zeros_like(xx), np.zeros_like(xx)
+        for k, hm in enumerate(hmins):
+            m = (xid == k // num) & (yid == k % num)
+            if not m.any():
+                continue
+            cx, cy = np.mean(x_all[xid_all == k // num]), np.mean(y[yid_all == k % num])
+            h[m] -= (h1 - hm) * (np.cos(bx * (xx[m] - cx)) * np.cos(by * (yy[m] - cy)))
+            dh_dx[m] += bx * (h1 - hm) * (np.sin(bx * (xx[m] - cx)) * np.cos(by * (yy[m] - cy)))
+            dh_dy[m] += by * (h1 - hm) * (np.cos(bx * (xx[m] - cx)) * np.sin(by * (yy[m] - cy)))
+    else:
+        raise IOError("Specify a valid geometry type")
+    return np.stack([h, dh_dx, dh_dy])
+
+
 class Topography:
     """Holds x, y, h, dh/dx, dh/dy (+ a zero deformation slot) as host arrays; the solver uploads
     ``full[:3]`` once (topography.py:180-255)."""
