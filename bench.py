@@ -178,9 +178,72 @@ def run_single(args):
             "workload": f"as the headline workload with a gap that varies in x and y (asperity, num 1) and a cross flow V = 0.05",
             "value": cells * args.steps / w2 / 1e6, "unit": "Mcell-updates/s", "ms_per_step": w2 / args.steps * 1e3,
             "kernel_ms": k2, "roofline": r2, "roofline_achieved_GBps": r2["achieved"], "roofline_frac": r2["frac"]}}
+        if not args.no_gp:
+            out["variants"]["gp_2048x2048_512pts"] = gp_variant(max(2, min(args.steps, 10)))
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline()
     return out
+
+
+GP_YAML = """
+options: {{silent: True, write_freq: 1000000}}
+grid: {{Nx: {n}, Ny: {n}, Lx: 0.1, Ly: 0.1, xE: ['D', 'N', 'N'], xW: ['D', 'N', 'N'], xE_D: 877.7007, xW_D: 877.7007,
+       yS: ['P', 'P', 'P'], yN: ['P', 'P', 'P']}}
+geometry: {{type: inclined, hmax: 6.6e-5, hmin: 1.e-5, U: 50., V: 0.}}
+numerics: {{CFL: 0.4, adaptive: 1, tol: 1.e-12, max_it: 100000}}
+properties: {{EOS: DH, shear: 0.0794, bulk: 0., rho0: 877.7007, P0: 101325., C1: 3.5e10, C2: 1.23}}
+gp:
+    press: {{atol: 1., rtol: 0.1, obs_stddev: 100., active_learning: False}}
+    shear: {{atol: 1., rtol: 0.1, obs_stddev: 1., active_learning: False}}
+db: {{init_size: {nt}, init_method: lhc, init_width: 0.01, init_seed: 123}}
+"""
+FP64_PEAK_TFLOPS = 78.6         # MI355X fp64 vector = fp64 matrix dense peak (SURVEY.md 7 H2 / 8d)
+
+
+def gp_variant(steps, n=2048, ntrain=512):
+    """BASELINE.json configs[3] (SURVEY.md 8d, cfg4 recipe): 2-D slider 2048^2 with pressure + wall-shear surrogates,
+    512 Latin-hypercube training points (seed 123, Mock laws), hyper-parameters fixed at their initial values.
+    Times whole MacCormack steps of the stage-wise pipeline (three posterior-mean passes per stage + one sound-speed
+    pass) and one predictive-variance pass.  Algorithmic flops per SURVEY 8(d): mean cells*N*(3d+12) per model and
+    evaluation (exp / sqrt count 1), variance cells*N^2."""
+    from gapflow_amd import Problem
+    with contextlib.redirect_stdout(sys.stderr):
+        prob = Problem.from_string(GP_YAML.format(n=n, nt=ntrain))
+        for m in prob._gp_models.values():
+            m.optimise = False
+        prob._pre_run()
+        prob.update()                                   # warm-up: first-use allocations, rocBLAS handle
+        prob._scalars()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            prob.update()
+        sc = prob._scalars()                            # drains the stream
+        t_step = (time.perf_counter() - t0) / steps
+        assert sc.invalid == 0 and prob.step == steps + 1, "GP steps were skipped or went invalid"
+        prob._gp_models['zz'].compute_variance(on_open_step=False)
+        t0 = time.perf_counter()
+        prob._gp_models['zz'].compute_variance(on_open_step=False)      # returns after a stream sync
+        t_var = time.perf_counter() - t0
+        del prob
+    cells = (n + 2)**2
+    evals = cells * ntrain * (2 * 3 + 1)                # model passes per step: 2 stages x 3 models + 1 sound speed
+    flops_mean = cells * ntrain * (2 * ((3 * 2 + 12) + 2 * (3 * 3 + 12)) + (3 * 2 + 12))
+    flops_var = cells * ntrain**2
+    return {
+        "workload": f"2D slider {n}x{n}, GP closures (pressure d=2, wall shear xz/yz d=3, Matern-3/2 ARD), {ntrain} training "
+                    "points (LHC seed 123), hyper-parameters fixed (BASELINE.json configs[3])",
+        "value": n * n / t_step / 1e6, "unit": "Mcell-updates/s", "ms_per_step": t_step * 1e3, "steps": steps,
+        "matern_kernel_evaluations_per_s": evals / t_step,
+        "roofline": {"bound": "fp64_valu", "achieved": flops_mean / t_step / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": flops_mean / t_step / 1e12 / FP64_PEAK_TFLOPS, "traffic": None,
+                     "kernel": "k_gp_mean (whole stage-wise step timed: ~95 % of it is the seven posterior-mean passes)",
+                     "algorithmic_flops_per_step": flops_mean},
+        "variance_pass": {"ms": t_var * 1e3, "model": "pressure",
+                          "roofline": {"bound": "mfma_f64", "achieved": flops_var / t_var / 1e12, "peak": FP64_PEAK_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": flops_var / t_var / 1e12 / FP64_PEAK_TFLOPS, "traffic": None,
+                                       "kernel": "k_gp_ks_tile + rocBLAS dgemm (L^-1 Ks) + k_gp_var_tile, 64 MiB tiles",
+                                       "algorithmic_flops_per_pass": flops_var}},
+    }
 
 
 def run_slabs(args, rank, world):
@@ -341,7 +404,8 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
-    ap.add_argument('--no-variants', action='store_true', help='skip the 2-D-gap variant of the workload')
+    ap.add_argument('--no-variants', action='store_true', help='skip the 2-D-gap and GP-closure variants of the workload')
+    ap.add_argument('--no-gp', action='store_true', help='skip the GP-closure variant (BASELINE.json configs[3])')
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

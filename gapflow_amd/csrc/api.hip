@@ -66,7 +66,8 @@ struct gpf_handle {
     double* halo = nullptr;                 // this slab's all-gather message: first row, last row (3 x pitch each), 8-double record
     StepState* st = nullptr;
     Partial* partials = nullptr;
-    unsigned int* arrive = nullptr;         // [0] blocks of k_ghost_fill that are done (finish_step), [1] same for k_begin_slab
+    unsigned int* arrive = nullptr;         // [0] blocks done: k_step2 (fused) / k_ghost_fill (finish_step); [1], [2]: k_begin_slab's arrivals and time-outs
+    long long p2p_timeout_ticks = P2P_TIMEOUT_TICKS;
     bool g1_ready = false;                  // g1 already holds the next step's stage-1 ghost values (k_begin_slab wrote them)
     Partial* block_partials = nullptr;      // one record per edge-kernel block
     int npartials = 0, nstrips = 0, nchunks = 0, rows_per_chunk = 0, nghost_blocks = 0;
@@ -132,6 +133,18 @@ static int blocks_for(long long n, int bs = 256, int cap = 4096) {
     case GPF_EOS_BWR: { constexpr int EOS_ = EOS_BWR; __VA_ARGS__; } break;                            \
     default: { constexpr int EOS_ = EOS_BAYADA; __VA_ARGS__; } break;                                  \
     }
+
+// slip-length field x piezo-viscosity: the edge kernels are specialised like the step kernel they serve
+#define LS_PIEZO_DISPATCH(ls, pz, ...)                                                                  \
+    do {                                                                                                \
+        if (ls) {                                                                                       \
+            constexpr bool LS_ = true;                                                                  \
+            if (pz) { constexpr bool PZ_ = true; __VA_ARGS__; } else { constexpr bool PZ_ = false; __VA_ARGS__; }     \
+        } else {                                                                                        \
+            constexpr bool LS_ = false;                                                                 \
+            if (pz) { constexpr bool PZ_ = true; __VA_ARGS__; } else { constexpr bool PZ_ = false; __VA_ARGS__; }     \
+        }                                                                                               \
+    } while (0)
 
 // ---------------------------------------------------------------------------------------------
 extern "C" const char* gpf_last_error(void) { return g_err.c_str(); }
@@ -218,8 +231,8 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
     h->nghost_blocks = std::max(1, std::min(64, (2 * (L.Ny + 2) + 2 * L.Nx + 255) / 256));
     HIP_TRY_C(hipMalloc(&h->partials, (size_t)h->npartials * sizeof(Partial)));
     HIP_TRY_C(hipMemset(h->partials, 0, (size_t)h->npartials * sizeof(Partial)));
-    HIP_TRY_C(hipMalloc(&h->arrive, 2 * sizeof(unsigned int)));
-    HIP_TRY_C(hipMemset(h->arrive, 0, 2 * sizeof(unsigned int)));
+    HIP_TRY_C(hipMalloc(&h->arrive, 4 * sizeof(unsigned int)));
+    HIP_TRY_C(hipMemset(h->arrive, 0, 4 * sizeof(unsigned int)));
     HIP_TRY_C(hipMalloc(&h->block_partials, 1024 * sizeof(Partial)));
     h->nspart = 1024;
     HIP_TRY_C(hipMalloc(&h->spart, (size_t)(h->nspart + 8) * sizeof(ScalarPartial)));
@@ -752,7 +765,7 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     const int nsend = slab ? std::min((6 * L.pitch + 1023) / 1024, 256) : 0;        // block_partials holds 1024
     WaitArgs w;
     w.qa = h->q[0]; w.qb = h->q[1]; w.st = h->st; w.log = h->log; w.log_base = log_base; w.log_cap = h->log_cap;
-    w.L = L; w.E = h->E; w.honor_stop = honor_stop; w.arrive = h->arrive + 1; w.p2p = f.p2p;
+    w.L = L; w.E = h->E; w.honor_stop = honor_stop; w.arrive = h->arrive + 1; w.timeout_ticks = h->p2p_timeout_ticks; w.p2p = f.p2p;
     w.gathered = nullptr; w.msg_len = 0; w.nranks = 0; w.rank_lo = w.rank_hi = -1;
     const bool has_ls = h->Ls != nullptr;
     if (fused) {
@@ -767,8 +780,7 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     }
     EOS_DISPATCH(h->cfg.eos, {
         if (!h->g1_ready) {
-            if (has_ls) hipLaunchKernelGGL((k_ghost_stage1<EOS_, true>), ggrid, dim3(256), 0, h->stream, g, h->P);
-            else hipLaunchKernelGGL((k_ghost_stage1<EOS_, false>), ggrid, dim3(256), 0, h->stream, g, h->P);
+            LS_PIEZO_DISPATCH(has_ls, h->cfg.piezo != 0, hipLaunchKernelGGL((k_ghost_stage1<EOS_, LS_, PZ_>), ggrid, dim3(256), 0, h->stream, g, h->P));
         }
         if (ev0) hipEventRecord(ev0, h->stream);
         if (two) {
@@ -780,8 +792,7 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
         if (ev1) hipEventRecord(ev1, h->stream);
         hipLaunchKernelGGL((k_ghost_fill<EOS_>), dim3(h->nghost_blocks + nsend), dim3(256), 0, h->stream, gf, f, h->nghost_blocks, h->P);
         if (p2p) {                          // wait for the peers, commit, stage-1 ghost data of the next step
-            if (has_ls) hipLaunchKernelGGL((k_begin_slab<EOS_, true, true>), ggrid, dim3(256), 0, h->stream, g, w, h->P);
-            else hipLaunchKernelGGL((k_begin_slab<EOS_, false, true>), ggrid, dim3(256), 0, h->stream, g, w, h->P);
+            LS_PIEZO_DISPATCH(has_ls, h->cfg.piezo != 0, hipLaunchKernelGGL((k_begin_slab<EOS_, LS_, PZ_, true>), ggrid, dim3(256), 0, h->stream, g, w, h->P));
         }
     });
     h->g1_ready = p2p;                  // k_begin_slab has prepared the next step's ghost data

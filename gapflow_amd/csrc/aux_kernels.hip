@@ -471,7 +471,8 @@ struct WaitArgs {
     LogEntry* log; long long log_base, log_cap;
     Layout L; Edges E;
     int honor_stop;
-    unsigned int* arrive;
+    unsigned int* arrive;       // [0] blocks done, [1] blocks whose wait for a peer timed out
+    long long timeout_ticks;    // bound on the wait for the peers' flags (100 MHz constant clock)
     P2PArgs p2p;                // MAILBOX source: rank ids, mailboxes, message counter
     const double* gathered;     // all-gather source: nranks messages [first row | last row | record] of msg_len doubles
     long long msg_len;
@@ -479,7 +480,7 @@ struct WaitArgs {
 };
 // MAILBOX: rows and records are waited for in this rank's mailbox (peer-to-peer transport); otherwise they are read from
 // the buffer an all-gather has filled before this launch (same layout as gpf_slab_message, rank order).
-template <int EOS, bool HAS_LS, bool MAILBOX>
+template <int EOS, bool HAS_LS, bool PIEZO, bool MAILBOX>
 __global__ __launch_bounds__(256) void k_begin_slab(const GhostArgs g, const WaitArgs a, const Phys P) {
     __shared__ int missing, last;
     __shared__ double tiles[2][3][64];
@@ -501,16 +502,17 @@ __global__ __launch_bounds__(256) void k_begin_slab(const GhostArgs g, const Wai
             ok = __hip_atomic_load(&hd->flag[slot][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= n;
             if (ok) break;
             __builtin_amdgcn_s_sleep(2);
-            if ((++probes & 255) == 0 && wall_clock64() - t0 > P2P_TIMEOUT_TICKS) break;
+            if ((++probes & 255) == 0 && wall_clock64() - t0 > a.timeout_ticks) break;
         }
         if (!ok) atomicAdd(&missing, 1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     }
     __syncthreads();
-    if (missing) {                      // a peer never delivered: stop this handle instead of spinning forever
-        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) st->invalid = INVALID_PEER_TIMEOUT;
-        return;
-    }
+    // A peer that never delivers must stop this handle, and the decision must be ONE decision: blocks time out on their
+    // own clocks, so a flag that lands near the deadline is seen by some blocks and missed by others.  Every block --
+    // timed out or not -- therefore goes through the arrival counter below; a block that missed a flag skips its share of
+    // the work and says so in a second counter, and the last block to arrive commits only if nobody missed anything.
+    const bool timed_out = missing != 0;
     // what the commit will decide (identical in every block and on every rank)
     double ekin = 0.0, v2 = 0.0, c2 = 0.0;
     int flags = 0;
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(256) void k_begin_slab(const GhostArgs g, const Wai
     if (v2 == inf) v2 = __builtin_nan("");
     if (c2 == inf) c2 = __builtin_nan("");
     const int nblocks = gridDim.x * gridDim.y, block = blockIdx.y * gridDim.x + blockIdx.x;
-    if ((flags & 3) == 0) {
+    if (!timed_out && (flags & 3) == 0) {
         double* q = st->parity ? a.qa : a.qb;           // the field the step has produced (current after the commit)
         // my row 0 is the lower neighbour's LAST row, my row Nx+1 the upper neighbour's FIRST row
         const double* row_lo = !(rank_lo >= 0 && a.E.halo[0]) ? nullptr
@@ -544,16 +546,28 @@ __global__ __launch_bounds__(256) void k_begin_slab(const GhostArgs g, const Wai
         MailField fld;
         fld.q = q; fld.L = L; fld.row_lo = row_lo; fld.row_hi = row_hi;
         const int ntiles = (L.Ny + L.Nx + 63) / 64;
-        for (int tile = block; tile < ntiles; tile += nblocks) ghost_stage1_tile<EOS, HAS_LS>(fld, g, P, D, tile * 64, dt, tiles);
+        for (int tile = block; tile < ntiles; tile += nblocks) ghost_stage1_tile<EOS, HAS_LS, PIEZO>(fld, g, P, D, tile * 64, dt, tiles);
     }
     // the last block to get here writes the committed state (the others have read everything they need from it)
     __syncthreads();
-    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nblocks - 1 ? 1 : 0;
+    if (threadIdx.x == 0) {
+        if (timed_out) {
+            __hip_atomic_fetch_add(a.arrive + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the miss is counted before this block arrives
+        }
+        last = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nblocks - 1 ? 1 : 0;
+    }
     __syncthreads();
     if (last && threadIdx.x == 0) {
+        const unsigned int misses = __hip_atomic_load(a.arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (MAILBOX) *c.seq = n;
-        commit_step(st, ekin, v2, c2, flags, a.log, a.log_base, a.log_cap);
+        __hip_atomic_store(a.arrive + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (misses) {
+            st->invalid = INVALID_PEER_TIMEOUT;         // no commit, no sequence advance: the handle stops here
+        } else {
+            if (MAILBOX) *c.seq = n;
+            commit_step(st, ekin, v2, c2, flags, a.log, a.log_base, a.log_cap);
+        }
     }
 }
 

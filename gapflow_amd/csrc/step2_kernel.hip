@@ -299,9 +299,9 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
         const double u0 = lane_from_below(fy[1][0]), u1 = lane_from_below(fy[1][1]), u2 = lane_from_below(fy[1][2]);
         const double up[2][3] = {{u0, u1, u2}, {fy[0][0], fy[0][1], fy[0][2]}};
         for (int k = 0; k < 2; ++k) {
-            q1[k][0] = r1.rho[k] - dt * (cx * (r1.jx[k] - r0.jx[k]) + cy * (fy[k][0] - up[k][0]) - f1[k].s0);
-            q1[k][1] = r1.jx[k] - dt * (cx * (f1[k].fx1 - f0[k].fx1) + cy * (fy[k][1] - up[k][1]) - f1[k].s1);
-            q1[k][2] = r1.jy[k] - dt * (cx * (f1[k].fx2 - f0[k].fx2) + cy * (fy[k][2] - up[k][2]) - f1[k].s2);
+            q1[k][0] = predictor_value(r1.rho[k], dt, cx, r1.jx[k] - r0.jx[k], cy, fy[k][0] - up[k][0], f1[k].s0);
+            q1[k][1] = predictor_value(r1.jx[k], dt, cx, f1[k].fx1 - f0[k].fx1, cy, fy[k][1] - up[k][1], f1[k].s1);
+            q1[k][2] = predictor_value(r1.jy[k], dt, cx, f1[k].fx2 - f0[k].fx2, cy, fy[k][2] - up[k][2], f1[k].s2);
             for (int c = 0; c < 3; ++c) stash[c][2 * lane + k] = q1[k][c];
         }
     }
@@ -361,9 +361,9 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
             const double u0 = lane_from_below(fy[1][0]), u1 = lane_from_below(fy[1][1]), u2 = lane_from_below(fy[1][2]);
             const double up[2][3] = {{u0, u1, u2}, {fy[0][0], fy[0][1], fy[0][2]}};
             for (int k = 0; k < 2; ++k) {
-                q1[k][0] = cur.rho[k] - dt * (cx * (cur.jx[k] - fx1p[k][0]) + cy * (fy[k][0] - up[k][0]) - f[k].s0);
-                q1[k][1] = cur.jx[k] - dt * (cx * (f[k].fx1 - fx1p[k][1]) + cy * (fy[k][1] - up[k][1]) - f[k].s1);
-                q1[k][2] = cur.jy[k] - dt * (cx * (f[k].fx2 - fx1p[k][2]) + cy * (fy[k][2] - up[k][2]) - f[k].s2);
+                q1[k][0] = predictor_value(cur.rho[k], dt, cx, cur.jx[k] - fx1p[k][0], cy, fy[k][0] - up[k][0], f[k].s0);
+                q1[k][1] = predictor_value(cur.jx[k], dt, cx, f[k].fx1 - fx1p[k][1], cy, fy[k][1] - up[k][1], f[k].s1);
+                q1[k][2] = predictor_value(cur.jy[k], dt, cx, f[k].fx2 - fx1p[k][2], cy, fy[k][2] - up[k][2], f[k].s2);
                 fx1p[k][0] = cur.jx[k]; fx1p[k][1] = f[k].fx1; fx1p[k][2] = f[k].fx2;
             }
             if (ghost_strip) {

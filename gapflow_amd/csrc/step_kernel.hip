@@ -70,6 +70,13 @@ __device__ __forceinline__ bool halted(const StepState* st, int honor_stop) {
     return st->invalid != 0 || (honor_stop && (st->converged || st->step >= st->max_it));
 }
 
+// q - dt (cx dFx + cy dFy - S): the predictor's update (problem.py:558) with its contractions spelled out, so that every
+// kernel that forms a stage-1 value -- the march of k_step2, its ghost-row prologue, k_ghost_stage1 / k_begin_slab for
+// slabs -- rounds it identically: an N-slab run is then bit-identical to the 1-slab run of the same problem.
+__device__ __forceinline__ double predictor_value(double q, double dt, double cx, double dfx, double cy, double dfy, double s) {
+    return fma(-dt, fma(cx, dfx, fma(cy, dfy, -s)), q);
+}
+
 // direction of the predictor of step number `step` (problem.py:521-522)
 __device__ __forceinline__ int direction_of_step(const StepState* st, long long step) {
     if (st->mc_order == 0) return (step % 2 == 0) ? 1 : -1;
@@ -352,7 +359,9 @@ __device__ __forceinline__ Stage1Item stage1_item(const GhostArgs& a, int D, int
 // One tile of 64 work items by a 256-thread block.  The three closures of an item are evaluated by three different
 // WAVES (wave 0: source cell, wave 1: x-upwind, wave 2: y-upwind; wave 3 idles), which cuts the dependent arithmetic
 // chain of this latency-bound job to a third; the upwind fluxes travel through LDS.
-template <int EOS, bool HAS_LS, class Field>
+// PIEZO and the closure variant (with source term) are the march's own, so that a value formed here is rounded exactly
+// like the same value formed by the stencil on the other side of a slab boundary.
+template <int EOS, bool HAS_LS, bool PIEZO, class Field>
 __device__ __forceinline__ void ghost_stage1_tile(const Field& fld, const GhostArgs& a, const Phys& P, int D, int t0, double dt,
                                                   double (*sm)[3][64]) {
     const Layout& L = a.L;
@@ -374,34 +383,33 @@ __device__ __forceinline__ void ghost_stage1_tile(const Field& fld, const GhostA
     if (it.active) {
         if (role == 0) {
             cell(it.ix_src, it.iy_src, it.ts, it.ls, c);
-            cell_closure<EOS, true, HAS_LS, true>(c, P, f);
+            cell_closure<EOS, true, HAS_LS, PIEZO>(c, P, f);
         } else if (role == 1) {
             cell(it.ix_up, it.iy_src, it.tu, it.lu, c);
-            cell_closure<EOS, false, HAS_LS, true>(c, P, f);
+            cell_closure<EOS, true, HAS_LS, PIEZO>(c, P, f);
             sm[0][0][lane] = c.jx; sm[0][1][lane] = f.fx1; sm[0][2][lane] = f.fx2;
         } else if (role == 2) {
             cell(it.ix_src, it.iy_src - D, it.ts, it.ls, c);
-            cell_closure<EOS, false, HAS_LS, true>(c, P, f);
+            cell_closure<EOS, true, HAS_LS, PIEZO>(c, P, f);
             sm[1][0][lane] = c.jy; sm[1][1][lane] = f.fx2; sm[1][2][lane] = f.fy2;
         }
     }
     __syncthreads();
     if (it.active && role == 0) {
         const double cx = (double)D * P.inv_dx, cy = (double)D * P.inv_dy;
-        const double A[3] = {c.rho, c.jx, c.jy};
-        double R[3];
-        R[0] = cx * (c.jx - sm[0][0][lane]) + cy * (c.jy - sm[1][0][lane]) - f.s0;
-        R[1] = cx * (f.fx1 - sm[0][1][lane]) + cy * (f.fx2 - sm[1][1][lane]) - f.s1;
-        R[2] = cx * (f.fx2 - sm[0][2][lane]) + cy * (f.fy2 - sm[1][2][lane]) - f.s2;
+        double v[3];
+        v[0] = predictor_value(c.rho, dt, cx, c.jx - sm[0][0][lane], cy, c.jy - sm[1][0][lane], f.s0);
+        v[1] = predictor_value(c.jx, dt, cx, f.fx1 - sm[0][1][lane], cy, f.fx2 - sm[1][1][lane], f.s1);
+        v[2] = predictor_value(c.jy, dt, cx, f.fx2 - sm[0][2][lane], cy, f.fy2 - sm[1][2][lane], f.s2);
         double* g = it.row ? a.g1x : a.g1y;
         const int stride = it.row ? L.pitch : L.Nx + 2;
-        for (int k = 0; k < 3; ++k) g[k * stride + it.out] = ghost_rule(a.E, it.edge, k, A[k] - dt * R[k]);
+        for (int k = 0; k < 3; ++k) g[k * stride + it.out] = ghost_rule(a.E, it.edge, k, v[k]);
     }
     __syncthreads();                // the LDS tile is free again
 }
 
 // stage-1 ghost data of the step about to run, from the stored field (ghost cells and halo rows included)
-template <int EOS, bool HAS_LS>
+template <int EOS, bool HAS_LS, bool PIEZO>
 __global__ __launch_bounds__(256) void k_ghost_stage1(const GhostArgs a, const Phys P) {
     __shared__ double sm[2][3][64];
     if (halted(a.st, a.honor_stop)) return;
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(256) void k_ghost_stage1(const GhostArgs a, const P
     const int D = predictor_direction(a.st);
     const double dt = a.st->dt;
     const int ntiles = (L.Ny + L.Nx + 63) / 64;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) ghost_stage1_tile<EOS, HAS_LS>(fld, a, P, D, tile * 64, dt, sm);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) ghost_stage1_tile<EOS, HAS_LS, PIEZO>(fld, a, P, D, tile * 64, dt, sm);
 }
 
 }  // namespace gpf

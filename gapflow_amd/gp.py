@@ -114,15 +114,11 @@ class Mock:
     dtool_basepath = property(lambda self: self._dtool_basepath)
 
     def _write_dataset(self, X, Y, Ye, tag):
-        """One directory per run with the run's inputs and outputs in README.yml, as md/base.py:128-188 leaves them
-        (name, README keys X / Y / Yerr / parameters / owners / dates).  The `.dtool` administrative files follow the
-        dtool on-disk layout as far as it is known here without dtoolcore (absent offline, so unverified against it);
-        this package itself only needs README.yml to reload a database."""
-        import getpass
-        import json
-        import uuid
+        """One directory per run holding a README.yml with the run's inputs and outputs (keys X / Y / Yerr / parameters, the
+        ones md/base.py:128-188 records), which is all this package needs to reload a database.  It is NOT a dtool
+        dataset: dtool persistence is out of scope and nothing of dtool's own on-disk
+        format is imitated here."""
         import yaml
-        from datetime import date
         now = datetime.now()
         name = f'{now.strftime("%Y%m%d_%H%M%S")}_{self.name}-{int(tag):03}'
         root = os.path.join(self._dtool_basepath, name)
@@ -130,25 +126,12 @@ class Mock:
         while os.path.exists(root):         # two runs within the same second and tag
             k += 1
             root = os.path.join(self._dtool_basepath, f'{name}_{k}')
-        os.makedirs(os.path.join(root, 'data'))
-        os.makedirs(os.path.join(root, '.dtool'))
-        today = date.today()
-        try:
-            expires = today.replace(year=today.year + 10)
-        except ValueError:                  # 29 February
-            expires = today.replace(year=today.year + 10, day=28)
+        os.makedirs(root)
         plain = lambda a: [float(v) for v in np.asarray(a, float).ravel()]
-        readme = {'owners': [{'username': getpass.getuser()}], 'creation_date': today, 'expiration_date': expires,
-                  'parameters': {k_: (v if isinstance(v, (int, float, str, bool, dict, list)) else str(v)) for k_, v in self.params.items()},
+        readme = {'parameters': {k_: (v if isinstance(v, (int, float, str, bool, dict, list)) else str(v)) for k_, v in self.params.items()},
                   'X': plain(X), 'Y': plain(Y), 'Yerr': plain(Ye)}
         with open(os.path.join(root, 'README.yml'), 'w') as f:
             yaml.safe_dump(readme, f)
-        admin = {'uuid': str(uuid.uuid4()), 'dtoolcore_version': '3.18.2', 'name': os.path.basename(root), 'type': 'dataset',
-                 'creator_username': getpass.getuser(), 'created_at': now.timestamp(), 'frozen_at': datetime.now().timestamp()}
-        with open(os.path.join(root, '.dtool', 'dtool'), 'w') as f:
-            json.dump(admin, f)
-        with open(os.path.join(root, '.dtool', 'manifest.json'), 'w') as f:
-            json.dump({'dtoolcore_version': admin['dtoolcore_version'], 'hash_function': 'md5sum_hexdigest', 'items': {}}, f)
 
     def _evaluator(self):
         if self._eval is None:
@@ -190,9 +173,10 @@ class Mock:
 
 
 class Database:
-    """Training data of all surrogates (db.py:46-369).  With a `dtool_path` every run is also kept as a dataset
-    directory below it and an existing directory is loaded on construction (db.py:79-103); without one the database
-    lives in memory until a Problem gives it `<output>/train` (problem.py:158-161)."""
+    """Training data of all surrogates (db.py:46-369).  With a `dtool_path` every run is also kept as a plain directory
+    with a README.yml below it and an existing directory is loaded on construction (the role of db.py:79-103; dtool
+    itself is out of scope); without one the database lives in memory until a Problem gives it `<output>/train`
+    (problem.py:158-161)."""
 
     def __init__(self, md, db, num_extra_features=1):
         self._md, self._db = md, db
@@ -268,7 +252,12 @@ class Database:
         # `Xtest` is the (ncell, 7) feature table of all cells, or an object that serves its column means and rows on
         # demand (slab.py: the whole domain's table is never built per rank)
         lazy = hasattr(Xtest, 'column_mean')
-        mean = Xtest.column_mean if lazy else (lambda k: np.mean(Xtest[:, k]))
+        def dense_mean(k):
+            # a uniform column (the initial field) has its own value as mean: exact, and therefore the same number on
+            # every slab (np.mean of n equal values can be an ulp off, depending on n)
+            col = Xtest[:, k]
+            return float(col[0]) if (col == col[0]).all() else float(np.mean(col))
+        mean = Xtest.column_mean if lazy else dense_mean
         if dim == 1:
             flux, active = mean(1), [0, 1]
         else:
@@ -339,6 +328,7 @@ class Surrogate:
         self.maximum_variance = np.inf
         self.variance_tol = 0.0
         self._var_valid = False
+        self._var_computed = False      # a variance field exists on the device (possibly of an earlier state: gp.py:406-414)
         ref = datetime.now()
         self.cumtime_train = self.cumtime_infer = ref - ref
         self.history = {k: [] for k in ('step', 'database_size', 'variance', 'obs_stddev', 'maximum_variance', 'variance_tol')}
@@ -438,6 +428,7 @@ class Surrogate:
         self.maximum_variance = mv.value
         self.variance_tol = max(self.atol * self.Yerr * self.Yscale, self.rtol * self.Yscale)**2
         self._var_valid = True
+        self._var_computed = True
 
     @property
     def variance(self):

@@ -7,6 +7,8 @@ The reference writes through muGrid's FileIONetCDF (problem.py:185-205, 629); it
     pressure        (frame, Nx+2, Ny+2)
     wall_stress_xz  (frame, 12, 1, Nx+2, Ny+2)     wall_stress_yz likewise
     topography      (frame, 4, 1, Nx+2, Ny+2)      in topo.nc
+    pressure_var, wall_stress_xz_var, wall_stress_yz_var   (frame, Nx+2, Ny+2)   only with the matching surrogate
+                    (problem.py:196-203; viz/plotting.py:340-348 draws its uncertainty bands from them)
 
 netCDF4 is not available in this environment, so frames are written as NetCDF-3 (64-bit offset)
 through scipy.io.netcdf_file, which netCDF4.Dataset opens transparently.
@@ -40,6 +42,12 @@ class FieldWriter:
         self._pre = self._f.createVariable('pressure', 'f8', ('frame', 'nx', 'ny'))
         self._wxz = self._f.createVariable('wall_stress_xz', 'f8', ('frame', 'tensor_dim__wall_stress-0', 'subpt__1', 'nx', 'ny'))
         self._wyz = self._f.createVariable('wall_stress_yz', 'f8', ('frame', 'tensor_dim__wall_stress-0', 'subpt__1', 'nx', 'ny'))
+        # predictive variances of the surrogates, as last evaluated (the reference writes its stored field, which is refreshed
+        # one step before every output frame: problem.py:530, stress.py:353-358, 617-620)
+        self._var = {}
+        for name, var in (('xz', 'wall_stress_xz_var'), ('yz', 'wall_stress_yz_var'), ('zz', 'pressure_var')):
+            if name in getattr(problem, '_gp_models', {}):
+                self._var[name] = self._f.createVariable(var, 'f8', ('frame', 'nx', 'ny'))
         self._n = 0
 
     @staticmethod
@@ -58,6 +66,9 @@ class FieldWriter:
         self._pre[k] = p.pressure.pressure
         self._wxz[k] = p.wall_stress_xz.full[:, None]
         self._wyz[k] = p.wall_stress_yz.full[:, None]
+        for name, v in self._var.items():
+            m = p._gp_models[name]
+            v[k] = m.variance if m._var_computed else np.zeros(p._shape)
         self._n += 1
         self._f.flush()
         if self._topo_file is not None:

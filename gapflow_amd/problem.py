@@ -246,13 +246,19 @@ class Problem:
                 self._closures_stale = True
 
     def _mark_device_advanced(self):
+        """The device field has moved on: the host mirror is stale until `q` is read again.  In the reference `q` is the
+        live field, so `q = p.q; p.update(); q[0] *= 1.01` edits the NEW state; here that array still holds the old one
+        and the edit could only be dropped or misapplied.  The stale mirror is therefore made read-only -- such an edit
+        raises at once -- and becomes writable (and current) again with the next read of `p.q`."""
         self._device_newer = True
         self._closures_stale = True
+        self._q_host.flags.writeable = False
 
     @property
     def q(self):
         """Full density field (3, Nx+2, Ny+2): rho, jx, jy -- a writable host mirror."""
         if self._device_newer:
+            self._q_host.flags.writeable = True
             _lib.check(self._lib.gpf_download(self._h, _lib.FIELD_Q, _lib.as_dp(self._q_host), self._q_host.size))
             self._q_snapshot = self._q_host.copy()
             self._device_newer = False

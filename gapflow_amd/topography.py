@@ -179,6 +179,9 @@ class Topography:
 
     @h.setter
     def h(self, value):
+        # Assigning `topo.h = ...` re-differentiates and uploads (topography.py:273-280).  In-place edits of the arrays
+        # returned by `h` / `full` stay on the host until `update_gradients()` (or a re-assignment) is called.
+        self._sync()                # bring a stale mirror of an elastic gap up to date first, or it would overwrite `value`
         self._field[0] = value
         self.update_gradients()
 

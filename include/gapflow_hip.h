@@ -186,11 +186,16 @@ int gpf_elastic_update(gpf_handle* h);
  * between steps, so gpf_step_p2p(n) enqueues n complete steps at once.
  *   gpf_p2p_export   allocate this slab's mailbox, return its 64-byte IPC handle (exchange them with any transport)
  *   gpf_p2p_connect  map every rank's mailbox; ipc_handles = nranks x 64 bytes in rank order
- *   gpf_step_p2p     n steps; a peer that stays silent for 30 s marks the state invalid (gpf_state: invalid == 3)
+ *   gpf_step_p2p     n steps; a peer that stays silent for 30 s marks the state invalid (gpf_state: invalid == 3) --
+ *                    decided once per launch: every block reports, the last one to arrive stops the handle if ANY block
+ *                    missed a flag (no commit, no sequence advance), so a flag that lands at the deadline cannot split
+ *                    the blocks of one launch
+ *   gpf_p2p_set_timeout   the bound on that wait, in seconds (tests use a fraction of a second)
  * rank_lo / rank_hi as in gpf_step_commit. */
 int gpf_p2p_export(gpf_handle* h, void* ipc_handle, size_t handle_bytes);
 int gpf_p2p_connect(gpf_handle* h, int rank, int nranks, const void* ipc_handles, int rank_lo, int rank_hi);
 int gpf_step_p2p(gpf_handle* h, int64_t n, int honor_stop);
+int gpf_p2p_set_timeout(gpf_handle* h, double seconds);
 /* Stage-wise step of a slab (GP closures, shear thinning): after each gpf_stage_advance the rows a neighbour needs
  * are packed from the working field (gpf_stage_message -> the same message buffer), all-gathered by the caller and
  * scattered (gpf_stage_absorb); gpf_close_step_local averages, applies the local ghost rules and leaves this slab's

@@ -6,6 +6,7 @@ the published Matern-3/2 / Cholesky formulas, and re-run the reference's own sel
 (tests/test_inference.py:88-111)."""
 import ctypes as C
 import io
+import os
 
 import numpy as np
 import pytest
@@ -205,3 +206,25 @@ def test_database_addition_and_reload(hiplib, tmp_path, method):
     from oracle import closures as ocl
     p_ref = ocl.eos_pressure(db._Xtrain[:, 0], {'EOS': 'PL', 'rho0': 1.1853, 'P0': 101325., 'alpha': 0.})
     np.testing.assert_allclose(db._Ytrain[:, 0], p_ref, rtol=1e-12)
+
+
+def test_variance_fields_are_written_with_the_frames(hiplib, tmp_path):
+    """problem.py:196-203: with surrogates sol.nc also carries pressure_var / wall_stress_xz_var (/ _yz_var in 2-D), the
+    fields viz/plotting.py:340-348 reads for its uncertainty bands; refreshed one step before each frame (problem.py:530)."""
+    from scipy.io import netcdf_file
+    from gapflow_amd import Problem
+    sim = SIM2D.replace("options: {silent: True, write_freq: 1000}",
+                        f"options: {{output: {tmp_path}/run, write_freq: 4, use_tstamp: False, silent: False}}").replace('max_it: 100', 'max_it: 8')
+    prob = Problem.from_string(sim)
+    for m in prob._gp_models.values():
+        m.optimise = False
+    prob.run()
+    with netcdf_file(os.path.join(tmp_path, 'run', 'sol.nc'), 'r', mmap=False) as f:
+        nfr = f.variables['pressure'].shape[0]
+        assert nfr == 3                                                     # steps 0, 4, 8
+        for name, model in (('pressure_var', 'zz'), ('wall_stress_xz_var', 'xz'), ('wall_stress_yz_var', 'yz')):
+            v = f.variables[name]
+            assert v.shape == (nfr, 42, 26)
+            last = v[-1]
+            assert np.isfinite(last).all() and last.max() > 0.0 and last.min() > -1e-9 * last.max()
+            np.testing.assert_array_equal(last, prob._gp_models[model].variance)

@@ -283,3 +283,134 @@ def test_slab_run_with_surrogates_writes_the_same_frames(hiplib, tmp_path):
             va, vb = fa.variables[name][:], fb.variables[name][:]
             assert va.shape == vb.shape and va.shape[0] == 3, name          # frames at steps 0, 3, 6
             assert np.abs(va - vb).max() <= 1e-9 * np.abs(vb).max(), name
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize('p2p', [False, True], ids=['allgather', 'p2p'])
+def test_n_slabs_are_bitwise_the_one_slab_run(hiplib, tmp_path, p2p):
+    """Determinism across decompositions on an all-periodic problem: the field after 20 steps on 2 and on 3 slabs is
+    bit for bit the field of the 1-slab run.  Every stage-1 value -- whether the stencil forms it or the ghost kernels
+    on the far side of a seam -- goes through the same spelled-out FMA sequence (predictor_value, step_kernel.hip), dt
+    comes from exact maxima reduced in rank order, and only the kinetic-energy SUM (hence the residual) depends on the
+    partition."""
+    import torch.multiprocessing as mp
+    nsteps = 20
+    runs = {}
+    for world in (1, 2, 3):
+        out = tmp_path / f'w{world}'
+        out.mkdir()
+        mp.spawn(_slab_worker, args=(world, _free_port(), SIM, nsteps, str(out), p2p and world > 1), nprocs=world, join=True)
+        parts = [np.load(out / f'rank{r}.npz') for r in range(world)]
+        assert all(int(z['step']) == nsteps and int(z['invalid']) == 0 for z in parts)
+        runs[world] = (np.concatenate([z['q'][:, 1:-1] for z in parts], axis=1), [float(z['dt']) for z in parts])
+    q1, dt1 = runs[1]
+    for world in (2, 3):
+        qn, dtn = runs[world]
+        assert qn.shape == q1.shape
+        assert np.array_equal(qn, q1), f'{world} slabs: {np.abs(qn - q1).max():.3e} away from the 1-slab field'
+        assert all(d == dt1[0] for d in dtn)
+
+
+def _timeout_worker(rank, world, port, text, out_dir):
+    """Rank 0 steps once; rank 1 connects its mailbox and then never sends: rank 0's launch must stop the handle."""
+    import time
+    import torch
+    import torch.distributed as dist
+    from gapflow_amd import _lib
+    from gapflow_amd.slab import SlabProblem
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        slab = SlabProblem.from_string(text, device=0, dist=StagedGloo(dist, torch))
+        assert slab.connect_p2p(), 'HIP IPC mapping of the peers\' mailboxes failed'
+        slab.pre_run()
+        _lib.check(slab.lib.gpf_p2p_set_timeout(slab._h, 0.25))
+        if rank == 0:
+            t0 = time.perf_counter()
+            slab.advance(3)                     # three steps enqueued: the first waits and times out, the others are skipped
+            outcome = 'completed'
+            try:
+                slab.state()
+            except RuntimeError as e:
+                outcome = 'timeout' if 'did not deliver' in str(e) else f'other: {e}'
+            waited = time.perf_counter() - t0
+            sc = _lib.GpfScalars()
+            _lib.check(slab.lib.gpf_state(slab._h, C_byref(sc)))
+            # a second attempt on the stopped handle returns at once and changes nothing
+            slab.advance(2)
+            sc2 = _lib.GpfScalars()
+            _lib.check(slab.lib.gpf_state(slab._h, C_byref(sc2)))
+            np.savez(os.path.join(out_dir, 'timeout.npz'), outcome=outcome, waited=waited, step=sc.step, invalid=sc.invalid,
+                     step2=sc2.step, invalid2=sc2.invalid)
+        dist.barrier()                          # rank 1 keeps its mailbox mapped until rank 0 is done
+    finally:
+        dist.destroy_process_group()
+
+
+def C_byref(x):
+    import ctypes
+    return ctypes.byref(x)
+
+
+def test_silent_peer_stops_the_handle_once(hiplib, tmp_path):
+    """gpf_step_p2p against a peer that never delivers: the wait is bounded, EVERY block of the waiting
+    launch goes through the arrival counter, the last one records the time-out -- no commit, no sequence advance, the
+    arrival counters are back at zero -- and later launches see a stopped handle."""
+    import torch.multiprocessing as mp
+    mp.spawn(_timeout_worker, args=(2, _free_port(), SIM, str(tmp_path)), nprocs=2, join=True)
+    z = np.load(tmp_path / 'timeout.npz')
+    assert str(z['outcome']) == 'timeout', str(z['outcome'])
+    assert int(z['invalid']) == 3 and int(z['step']) == 0            # nothing was committed
+    assert int(z['invalid2']) == 3 and int(z['step2']) == 0
+    assert 0.2 < float(z['waited']) < 20.0, float(z['waited'])       # bounded by the configured 0.25 s, not by 30 s
+
+
+def _nccl_worker(rank, world, port, text, nsteps, out_dir, p2p):
+    import torch
+    import torch.distributed as dist
+    from gapflow_amd.slab import SlabProblem
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+    try:
+        slab = SlabProblem.from_string(text, device=rank)
+        if p2p:
+            assert slab.connect_p2p(), 'HIP IPC mapping of the peers\' mailboxes failed'
+        slab.pre_run()
+        slab.advance(nsteps)
+        st = slab.state()
+        np.savez(os.path.join(out_dir, f'rank{rank}.npz'), q=slab.local_q(), lo=slab.layout.lo, hi=slab.layout.hi,
+                 dt=st.dt, step=st.step, invalid=st.invalid)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('p2p', [False, True], ids=['allgather', 'p2p'])
+def test_two_gpus_over_rccl_match_serial(hiplib, tmp_path, p2p):
+    """The real thing where the box has it: one rank per GPU, RCCL (`nccl` backend) over xGMI, both transports.  Skipped
+    on the one-GPU development and test boxes -- nothing with more than one GPU has run on hardware so far."""
+    if hiplib.gpf_device_count() < 2:
+        pytest.skip('needs two GPUs')
+    import torch.multiprocessing as mp
+    from gapflow_amd import Problem
+    nsteps = 20
+    mp.spawn(_nccl_worker, args=(2, _free_port(), SIM, nsteps, str(tmp_path), p2p), nprocs=2, join=True)
+    serial = Problem.from_string(SIM)
+    serial._pre_run()
+    serial._advance(nsteps, honor_stop=False)
+    for r in range(2):
+        z = np.load(tmp_path / f'rank{r}.npz')
+        lo, hi = int(z['lo']), int(z['hi'])
+        assert int(z['step']) == nsteps and int(z['invalid']) == 0
+        for c in range(3):
+            scale = np.abs(serial.q[c]).max() or 1.
+            assert np.abs(z['q'][c] - serial.q[c, lo - 1:hi + 2]).max() <= 1e-11 * scale
+        np.testing.assert_allclose(z['dt'], serial.dt, rtol=1e-12)

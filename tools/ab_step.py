@@ -35,7 +35,7 @@ def main():
             e = dict(os.environ, **env)
             if lib:
                 e['GPF_LIB_PATH'] = os.path.join(ROOT, lib)
-            out = subprocess.run([sys.executable, 'bench.py', '--no-cpu', '--steps', str(steps)], cwd=ROOT, env=e,
+            out = subprocess.run([sys.executable, 'bench.py', '--no-cpu', '--no-gp', '--steps', str(steps)], cwd=ROOT, env=e,
                                  capture_output=True, text=True, timeout=600)
             if out.returncode != 0:
                 print(name, 'FAILED', out.stderr[-500:], flush=True)
