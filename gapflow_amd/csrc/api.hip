@@ -63,7 +63,9 @@ struct gpf_handle {
     // peer-to-peer slab transport (gpf_p2p_*): my mailbox, every rank's mailbox as mapped here, message counter
     struct { bool on = false; int nranks = 0, rank = 0, rank_lo = -1, rank_hi = -1; char* mine = nullptr;
              char* box[P2P_MAX_RANKS] = {}; unsigned long long* seq = nullptr; } p2p;
-    double* halo = nullptr;                 // this slab's all-gather message: first row, last row (3 x pitch each), 8-double record
+    double* halo = nullptr;                 // this slab's all-gather message: first row, last row (3 x pitch each), [thinning: density of
+                                            // the second and second-to-last row,] 8-double record
+    double* beyond = nullptr;               // thinning slabs: density one row beyond each outer row, [state | working field][2][pitch]
     StepState* st = nullptr;
     Partial* partials = nullptr;
     unsigned int* arrive = nullptr;         // [0] blocks done: k_step2 (fused) / k_ghost_fill (finish_step); [1], [2]: k_begin_slab's arrivals and time-outs
@@ -247,7 +249,7 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
 extern "C" int gpf_destroy(gpf_handle* h) {
     if (!h) return GPF_OK;
     hipSetDevice(h->cfg.device);
-    void* ptrs[] = {h->q[0], h->q[1], h->topo, h->topo_line, h->Ls, h->g1, h->seam, h->halo, h->st, h->partials, h->arrive, h->block_partials, h->spart,
+    void* ptrs[] = {h->q[0], h->q[1], h->topo, h->topo_line, h->Ls, h->g1, h->seam, h->halo, h->beyond, h->st, h->partials, h->arrive, h->block_partials, h->spart,
                     h->log, h->stage, h->fields, h->work, h->gpvar, h->gpscratch, h->gptile,
                     h->gp[0].Z, h->gp[0].alpha, h->gp[0].L, h->gp[1].Z, h->gp[1].alpha, h->gp[1].L,
                     h->gp[2].Z, h->gp[2].alpha, h->gp[2].L, h->gp[0].Linv, h->gp[1].Linv, h->gp[2].Linv};
@@ -411,6 +413,13 @@ static FieldPtrs field_ptrs(gpf_handle* h) {
 
 static int gp_launch_mean(gpf_handle* h, int which, const double* q, bool with_grad, double* c2_out);
 
+// thinning on a slab: the beyond rows that belong to field q (the working field of an open step, or the state)
+static const double* beyond_rows(gpf_handle* h, const double* q) {
+    if (!h->beyond || (h->E.halo[0] != 1 && h->E.halo[1] != 1)) return nullptr;
+    const bool working = h->step_open && q == h->q[h->open_parity ^ 1];
+    return h->beyond + (working ? 2 * h->L.pitch : 0);
+}
+
 static int launch_fields(gpf_handle* h, const double* q) {
     GPF_TRY(ensure_fields(h));
     const Layout& L = h->L;
@@ -419,8 +428,11 @@ static int launch_fields(gpf_handle* h, const double* q) {
     EOS_DISPATCH(h->cfg.eos, {
         if (h->cfg.thinning != GPF_THINNING_NONE) {
             hipLaunchKernelGGL((k_pressure<EOS_>), dim3(blocks_for(n)), dim3(256), 0, h->stream, q, F.p, L, h->P);
-            if (h->Ls) hipLaunchKernelGGL((k_fields_thinning<EOS_, true>), dim3(blocks_for(n)), dim3(256), 0, h->stream, q, h->topo, h->Ls, F, L, h->P, h->cfg.dx, h->cfg.dy);
-            else hipLaunchKernelGGL((k_fields_thinning<EOS_, false>), dim3(blocks_for(n)), dim3(256), 0, h->stream, q, h->topo, (const double*)nullptr, F, L, h->P, h->cfg.dx, h->cfg.dy);
+            if ((h->E.halo[0] == 1 || h->E.halo[1] == 1) && !h->beyond)
+                return fail(GPF_ERR_STATE, "shear thinning on a slab: upload the rows beyond the halo first (gpf_upload_beyond)");
+            const double* by = beyond_rows(h, q);
+            if (h->Ls) hipLaunchKernelGGL((k_fields_thinning<EOS_, true>), dim3(blocks_for(n)), dim3(256), 0, h->stream, q, h->topo, h->Ls, F, L, h->P, h->cfg.dx, h->cfg.dy, h->E.halo[0], h->E.halo[1], by);
+            else hipLaunchKernelGGL((k_fields_thinning<EOS_, false>), dim3(blocks_for(n)), dim3(256), 0, h->stream, q, h->topo, (const double*)nullptr, F, L, h->P, h->cfg.dx, h->cfg.dy, h->E.halo[0], h->E.halo[1], by);
         } else if (h->Ls) hipLaunchKernelGGL((k_fields<EOS_, true>), dim3(blocks_for(n)), dim3(256), 0, h->stream, q, h->topo, h->Ls, F, L, h->P);
         else hipLaunchKernelGGL((k_fields<EOS_, false>), dim3(blocks_for(n)), dim3(256), 0, h->stream, q, h->topo, (const double*)nullptr, F, L, h->P);
     });

@@ -244,6 +244,22 @@ struct FinishArgs {
 // (the 'write-through payload + counter + sc1 loads' form of the CDNA4 guide, Guideline 16 / MI355X_MICROARCH.md
 // "Valid forms").  Everything else these blocks store -- ghost cells, stage-1 pairs, the slab message -- is read by
 // LATER launches only.
+// Memory-model note.  The fast path orders these hand-offs by construction (write-through stores, drained with
+// s_waitcnt vmcnt(0) before the same lane's arrival add, sc1 loads after the add that identified the last arriver) rather
+// than through the HIP/LLVM memory model: relaxed agent-scope atomics carry no ordering of their own.  What is assumed of
+// gfx950: (1) a relaxed agent-scope atomic store is a write-through `global_store ... sc1` whose completion `vmcnt` counts;
+// (2) atomic adds of one lane to the same L2 are performed in issue order once earlier stores have drained; (3) a relaxed
+// agent-scope atomic load (`sc1`) is served from L2, past the CU's L1.  -DGPF_STRICT_ATOMICS builds the same kernels with
+// release / acquire orders on the arrival add and on the record loads (python -m gapflow_amd.build --variant strict
+// -DGPF_STRICT_ATOMICS; tests/test_gpu_extras.py runs the goldens on it when present): results must be identical.
+#ifdef GPF_STRICT_ATOMICS
+#define GPF_ORDER_ARRIVE __ATOMIC_ACQ_REL
+#define GPF_ORDER_LOAD __ATOMIC_ACQUIRE
+#else
+#define GPF_ORDER_ARRIVE __ATOMIC_RELAXED
+#define GPF_ORDER_LOAD __ATOMIC_RELAXED
+#endif
+
 __device__ __forceinline__ void publish_partial(Partial* slot, const Acc& acc) {      // one lane
     unsigned long long* w = reinterpret_cast<unsigned long long*>(slot);
     __hip_atomic_store(w + 0, (unsigned long long)__double_as_longlong(acc.ekin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -254,10 +270,10 @@ __device__ __forceinline__ void publish_partial(Partial* slot, const Acc& acc) {
 }
 __device__ __forceinline__ void merge_published(Acc& acc, const Partial* slot) {
     const unsigned long long* w = reinterpret_cast<const unsigned long long*>(slot);
-    const double ekin = __longlong_as_double((long long)__hip_atomic_load(w + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    const double v2 = __longlong_as_double((long long)__hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    const double c2 = __longlong_as_double((long long)__hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    const double fl = __longlong_as_double((long long)__hip_atomic_load(w + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const double ekin = __longlong_as_double((long long)__hip_atomic_load(w + 0, GPF_ORDER_LOAD, __HIP_MEMORY_SCOPE_AGENT));
+    const double v2 = __longlong_as_double((long long)__hip_atomic_load(w + 1, GPF_ORDER_LOAD, __HIP_MEMORY_SCOPE_AGENT));
+    const double c2 = __longlong_as_double((long long)__hip_atomic_load(w + 2, GPF_ORDER_LOAD, __HIP_MEMORY_SCOPE_AGENT));
+    const double fl = __longlong_as_double((long long)__hip_atomic_load(w + 3, GPF_ORDER_LOAD, __HIP_MEMORY_SCOPE_AGENT));
     acc.ekin += ekin; acc.v2 = nanmax(acc.v2, v2); acc.c2 = nanmax(acc.c2, c2); acc.flags |= (int)fl;
 }
 
@@ -312,7 +328,7 @@ __device__ inline void finish_step(const FinishArgs& f, Acc own, Acc* sm) {
     own = block_reduce(own, sm);        // its barriers also put every wave's drained row stores before the arrival
     if (threadIdx.x == 0) {
         publish_partial(f.block_partials + blockIdx.x, own);
-        last = __hip_atomic_fetch_add(f.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+        last = __hip_atomic_fetch_add(f.arrive, 1u, GPF_ORDER_ARRIVE, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
         if (last) __hip_atomic_store(f.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
@@ -434,6 +450,11 @@ struct HaloArgs {
     Layout L; Edges E;
     int honor_stop;
     int work_parity;            // -1: the buffer the fused step wrote (!parity); 0/1: that buffer (stage-wise step)
+    // shear thinning: the viscosity of a halo row needs grad p there, i.e. the density one row further into the
+    // neighbour.  The message then carries two more rows (density of the second and of the second-to-last owned row)
+    // and `beyond` receives the neighbours': [0] beyond row 0, [1] beyond row Nx+1 (pitch doubles each); else nullptr.
+    double* beyond;
+    int msg_rows;               // 6, or 8 with shear thinning (the two extra rows travel whether or not this slab uses them)
 };
 __global__ void k_halo_pack(const HaloArgs a) {
     if (a.st->invalid != 0 || (a.honor_stop && (a.st->converged || a.st->step >= a.st->max_it))) return;
@@ -444,18 +465,32 @@ __global__ void k_halo_pack(const HaloArgs a) {
         a.msg[c * a.L.pitch + i] = q[c * a.L.plane + (long long)1 * a.L.pitch + i];
         a.msg[(3 + c) * a.L.pitch + i] = q[c * a.L.plane + (long long)a.L.Nx * a.L.pitch + i];
     }
+    if (a.msg_rows == 8) {  // densities of the second and the second-to-last owned row (a one-row slab sends its only row)
+        a.msg[6 * a.L.pitch + i] = q[(long long)min(2, a.L.Nx) * a.L.pitch + i];
+        a.msg[7 * a.L.pitch + i] = q[(long long)max(a.L.Nx - 1, 1) * a.L.pitch + i];
+    }
 }
 __global__ void k_halo_unpack(const HaloArgs a) {
     if (a.st->invalid != 0 || (a.honor_stop && (a.st->converged || a.st->step >= a.st->max_it))) return;
     double* q = a.work_parity >= 0 ? (a.work_parity ? a.qb : a.qa) : (a.st->parity ? a.qa : a.qb);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.L.pitch) return;
-    const long long len = 6ll * a.L.pitch + 8;
+    const long long len = (long long)a.msg_rows * a.L.pitch + 8;
     for (int c = 0; c < 3; ++c) {
         if (a.E.halo[0] && a.rank_lo >= 0) q[c * a.L.plane + i] = a.gathered[a.rank_lo * len + (3 + c) * a.L.pitch + i];
         if (a.E.halo[1] && a.rank_hi >= 0)
             q[c * a.L.plane + (long long)(a.L.Nx + 1) * a.L.pitch + i] = a.gathered[a.rank_hi * len + c * a.L.pitch + i];
     }
+    if (a.beyond) {     // beyond my row 0: the lower neighbour's second-to-last row; beyond my row Nx+1: the upper one's second
+        if (a.E.halo[0] && a.rank_lo >= 0) a.beyond[i] = a.gathered[a.rank_lo * len + 7 * a.L.pitch + i];
+        if (a.E.halo[1] && a.rank_hi >= 0) a.beyond[a.L.pitch + i] = a.gathered[a.rank_hi * len + 6 * a.L.pitch + i];
+    }
+}
+
+// beyond rows of the new state = average of the working field's and the old state's, as the field itself (problem.py:563)
+__global__ void k_beyond_average(double* state, const double* work, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) state[i] = (work[i] + state[i]) / 2.0;
 }
 
 // Receiving side of a slab step (either transport), fused with the start of the NEXT step.  Every block waits (bounded)
@@ -555,7 +590,7 @@ __global__ __launch_bounds__(256) void k_begin_slab(const GhostArgs g, const Wai
             __hip_atomic_fetch_add(a.arrive + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the miss is counted before this block arrives
         }
-        last = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nblocks - 1 ? 1 : 0;
+        last = __hip_atomic_fetch_add(a.arrive, 1u, GPF_ORDER_ARRIVE, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nblocks - 1 ? 1 : 0;
     }
     __syncthreads();
     if (last && threadIdx.x == 0) {
@@ -655,9 +690,12 @@ __global__ __launch_bounds__(256) void k_pressure(const double* q, double* p, La
     }
 }
 
+// `beyond` (slabs only, else nullptr): density one row beyond row 0 ([0]) and beyond row Nx+1 ([1]) where that outer row
+// is a neighbour's interior row (halo kind 1): np.gradient's central difference of the undivided array reaches there.
 template <int EOS, bool HAS_LS>
 __global__ __launch_bounds__(256) void k_fields_thinning(const double* q, const double* topo, const double* Ls, FieldPtrs F,
-                                                         Layout L, Phys P, double dx, double dy) {
+                                                         Layout L, Phys P, double dx, double dy, int halo_lo, int halo_hi,
+                                                         const double* beyond) {
     const long long w = L.Ny + 2, n = (long long)(L.Nx + 2) * w;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int ix = (int)(i / w), iy = (int)(i % w);
@@ -670,7 +708,11 @@ __global__ __launch_bounds__(256) void k_fields_thinning(const double* q, const 
         // np.gradient, edge_order 1
         const int ixm = ix > 0 ? ix - 1 : ix, ixp = ix < L.Nx + 1 ? ix + 1 : ix;
         const int iym = iy > 0 ? iy - 1 : iy, iyp = iy < L.Ny + 1 ? iy + 1 : iy;
-        const double dpx = (F.p[L.at(ixp, iy)] - F.p[L.at(ixm, iy)]) / ((ixp - ixm) * dx);
+        double dpx = (F.p[L.at(ixp, iy)] - F.p[L.at(ixm, iy)]) / ((ixp - ixm) * dx);
+        if (beyond && ix == 0 && halo_lo == 1)
+            dpx = (F.p[L.at(1, iy)] - eos_pressure<EOS>(beyond[L.off + iy], P)) / (2 * dx);
+        if (beyond && ix == L.Nx + 1 && halo_hi == 1)
+            dpx = (eos_pressure<EOS>(beyond[L.pitch + L.off + iy], P) - F.p[L.at(L.Nx, iy)]) / (2 * dx);
         const double dpy = (F.p[L.at(ix, iyp)] - F.p[L.at(ix, iym)]) / ((iyp - iym) * dy);
         const double mu0 = (P.piezo == PIEZO_NONE) ? P.eta : piezo_eta(P.eta, (EOS == EOS_BAYADA) ? c.rho : pc, P);
         const double eta = thinning_eta(mu0, dpx, dpy, c.h, P);

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256, (TOPO == 1 ? GPF_K2_MINWAVES_LINE : GPF_K2_MIN
         Acc tot = red_sm[0];
         for (int i = 1; i < 4; ++i) { tot.ekin += red_sm[i].ekin; tot.v2 = fmax(tot.v2, red_sm[i].v2); tot.c2 = fmax(tot.c2, red_sm[i].c2); tot.flags |= red_sm[i].flags; }
         publish_partial(a.block_partials + blockIdx.x, tot);       // write-through + drained: see aux_kernels.hip
-        const unsigned int t = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int t = __hip_atomic_fetch_add(a.arrive, 1u, GPF_ORDER_ARRIVE, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (t == (unsigned int)nb - 1) ? 1 : 0;
         if (s_last) __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -239,9 +239,11 @@ class SlabProblem:
         shell.options, shell.numerics, shell.prop, shell.geo = input_dict['options'], input_dict['numerics'], prop, geo
         shell.grid = L.local_grid(grid)
         cfg = shell._make_config(device)
-        if cfg.thinning:
-            # the viscosity of a halo row depends on grad p there, i.e. on a second row of the neighbour
-            raise NotImplementedError("shear thinning needs a two-row halo; not available in slab mode")
+        # shear thinning: the viscosity of a halo row depends on grad p there, i.e. on a second row of the neighbour -- the
+        # stage-wise step then exchanges two rows per side (gpf_upload_beyond / gpf_stage_message) and is the only step
+        self._thinning = bool(cfg.thinning)
+        if self._thinning and L.nx < 2 and self.world > 1:
+            raise ValueError("shear thinning across slabs needs at least two rows per slab")
         cfg.halo_lo, cfg.halo_hi = L.kind_lo, L.kind_hi
         self.grid_local = shell.grid
         self._h = C.c_void_p()
@@ -263,6 +265,11 @@ class SlabProblem:
         q = np.empty((3,) + shape)
         q[0], q[1], q[2] = prop['rho0'], prop['rho0'] * geo['U'] / 2.0, prop['rho0'] * geo['V'] / 2.0
         self._upload(_lib.FIELD_Q, q)
+        if self._thinning:
+            beyond = _lib.f64c(np.full(grid['Ny'] + 2, prop['rho0']))          # the uniform initial field, one row further
+            for side, kind in ((0, L.kind_lo), (1, L.kind_hi)):
+                if kind == HALO_NEIGHBOUR:
+                    _lib.check(self.lib.gpf_upload_beyond(self._h, side, _lib.as_dp(beyond), beyond.size))
         nxg = grid['Nx']
         for side, kind, (r_src, r_up) in ((0, L.kind_lo, (nxg, nxg + 1)), (1, L.kind_hi, (1, 0))):
             if kind == HALO_SEAM:
@@ -403,7 +410,7 @@ class SlabProblem:
         self._pre_run_done = True
 
     def advance(self, n, honor_stop=False, write_freq=None):
-        if not self._gp_models:
+        if not self._gp_models and not self._thinning:
             return self.driver.advance(n, honor_stop)
         for _ in range(n):
             st = self.state()

@@ -200,6 +200,12 @@ int gpf_p2p_set_timeout(gpf_handle* h, double seconds);
  * are packed from the working field (gpf_stage_message -> the same message buffer), all-gathered by the caller and
  * scattered (gpf_stage_absorb); gpf_close_step_local averages, applies the local ghost rules and leaves this slab's
  * record in the message, gpf_close_step_commit reduces the gathered records and advances dt / residual / step. */
+/* Shear thinning (stress.py:170-192: eta depends on np.gradient(p)) gives the step a two-row reach in x: the viscosity of a
+ * slab's halo row needs the pressure one row further into the neighbour.  With cfg.thinning != 0 the stage messages carry
+ * two more rows (density of the second and second-to-last owned row; message length 8*pitch + 8) and the library keeps the
+ * neighbours' copies; gpf_upload_beyond seeds them for the initial state (side 0: beyond row 0, 1: beyond row Nx+1;
+ * Ny+2 densities).  Only the stage-wise calls serve such a slab (gpf_step_local / gpf_step_p2p refuse it). */
+int gpf_upload_beyond(gpf_handle* h, int side, const double* rho_row, size_t count);
 int gpf_stage_message(gpf_handle* h);
 int gpf_stage_absorb(gpf_handle* h, const void* gathered, int nranks, int rank_lo, int rank_hi);
 int gpf_close_step_local(gpf_handle* h);

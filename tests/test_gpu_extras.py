@@ -158,3 +158,38 @@ np.savez(sys.argv[1], q=p.q, dt=p.dt, ekin=p.kinetic_energy, residual=p.residual
     np.testing.assert_allclose(b['dt'], a['dt'], rtol=1e-13)
     np.testing.assert_allclose(b['simtime'], a['simtime'], rtol=1e-13)
     np.testing.assert_allclose(b['ekin'], a['ekin'], rtol=1e-12)
+
+
+def test_strict_atomics_build_gives_identical_results(hiplib, tmp_path):
+    """the in-launch hand-offs (per-block records -> last block) are ordered by write-through stores, a drained
+    arrival add and sc1 loads, not by the HIP memory model.  `python -m gapflow_amd.build --variant strict
+    -DGPF_STRICT_ATOMICS` builds the same kernels with release / acquire orders; both libraries must produce the same
+    fields, bit for bit, on a fused run (k_step2's in-kernel commit) -- run in two child processes because the library
+    path is read at import.  Skipped when the variant has not been built."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    strict = os.path.join(root, 'gapflow_amd', 'lib', 'variants', 'strict.so')
+    if not os.path.exists(strict):
+        pytest.skip('gapflow_amd/lib/variants/strict.so not built')
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+from test_gpu_parity import make_problem
+out = {{}}
+for name in ('slider2d_dn', 'seam2d_asperity', 'journal2d_periodic50_u10'):
+    prob, fx, meta = make_problem(name)
+    prob._advance(40, honor_stop=False)
+    out[name] = prob.q.copy(); out[name + '_dt'] = prob.dt; out[name + '_res'] = prob.residual
+np.savez(sys.argv[1], **out)
+"""
+    outs = []
+    for tag, lib in (('fast', None), ('strict', strict)):
+        env = dict(os.environ)
+        if lib:
+            env['GPF_LIB_PATH'] = lib
+        res = subprocess.run([sys.executable, '-c', code, str(tmp_path / f'{tag}.npz')], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append(np.load(tmp_path / f'{tag}.npz'))
+    for k in outs[0].files:
+        assert np.array_equal(outs[0][k], outs[1][k]), k

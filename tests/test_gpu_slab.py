@@ -414,3 +414,49 @@ def test_two_gpus_over_rccl_match_serial(hiplib, tmp_path, p2p):
             scale = np.abs(serial.q[c]).max() or 1.
             assert np.abs(z['q'][c] - serial.q[c, lo - 1:hi + 2]).max() <= 1e-11 * scale
         np.testing.assert_allclose(z['dt'], serial.dt, rtol=1e-12)
+
+
+THINNING_SLAB = """
+options: {{silent: True}}
+grid: {{Nx: 48, Ny: 10, Lx: 0.05, Ly: 0.01{bc}}}
+geometry: {{type: {geo}, U: 10., V: 1.}}
+numerics: {{CFL: 0.4, adaptive: 1, max_it: 100}}
+properties:
+    EOS: DH
+    shear: 0.05
+    bulk: 0.
+    rho0: 877.7007
+    thinning: {{name: {law}}}
+"""
+
+
+@pytest.mark.parametrize('law,bc,geo,world', [
+    ('Eyring, tauE: 5.e5', ", xE: ['D', 'N', 'N'], xW: ['D', 'N', 'N'], xE_D: 877.7007, xW_D: 877.7007", 'parabolic, hmin: 1.e-5, hmax: 4.e-5', 2),
+    ('Carreau, mu_inf: 1.e-3, lam: 1.e-5, a: 2., N: 0.6', ", xE: ['D', 'N', 'N'], xW: ['D', 'N', 'N'], xE_D: 877.7007, xW_D: 877.7007",
+     'parabolic, hmin: 1.e-5, hmax: 4.e-5', 3),
+    ('Eyring, tauE: 5.e5', '', 'journal, CR: 1.e-2, eps: 0.6', 3)], ids=['eyring-dirichlet-2', 'carreau-dirichlet-3', 'eyring-periodic-3'])
+def test_shear_thinning_across_slabs(hiplib, tmp_path, law, bc, geo, world):
+    """Shear thinning (stress.py:170-192, 314-326; viscosity.py:110-141): the viscosity needs np.gradient(p), so a slab's
+    halo row needs the neighbour's pressure one row further in -- a two-row halo, carried by the stage messages.  2 and 3
+    slabs against the one-handle run AND the oracle, 12 steps."""
+    import torch.multiprocessing as mp
+    from gapflow_amd import Problem
+    from oracle.problem import OracleProblem
+    text = THINNING_SLAB.format(law=law, bc=bc, geo=geo)
+    nsteps = 12
+    mp.spawn(_slab_worker, args=(world, _free_port(), text, nsteps, str(tmp_path)), nprocs=world, join=True)
+    serial, cpu = Problem.from_string(text), OracleProblem.from_string(text)
+    serial._pre_run()
+    cpu._pre_run()
+    for _ in range(nsteps):
+        serial.update()
+        cpu.update()
+    for r in range(world):
+        z = np.load(tmp_path / f'rank{r}.npz')
+        lo, hi = int(z['lo']), int(z['hi'])
+        assert int(z['step']) == nsteps and int(z['invalid']) == 0
+        for c in range(3):
+            scale = np.abs(serial.q[c]).max() or 1.
+            assert np.abs(z['q'][c] - serial.q[c, lo - 1:hi + 2]).max() <= 1e-12 * scale, f'rank {r} comp {c} vs serial'
+            assert np.abs(z['q'][c] - cpu.q[c, lo - 1:hi + 2]).max() <= 1e-9 * scale, f'rank {r} comp {c} vs oracle'
+        np.testing.assert_allclose(z['dt'], serial.dt, rtol=1e-12)

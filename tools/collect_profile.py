@@ -1,13 +1,15 @@
 """Collect the profile set the benchmark numbers are judged against, on the GPU box:
 
-    python tools/collect_profile.py gpurun_out/profile_<name> [--planes]
+    cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && python tools/collect_profile.py gpurun_out/profile_<name>
 
-  bench.json                 python bench.py (full default run, cpu_baseline included)
-  kernel_stats.csv           rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu --no-variants
-  pmc_means_per_launch.json  per-kernel means of the counters, one rocprofv3 --pmc pass per group (never combined
-                             with other traces), python3 bench.py --steps 6 --warmup 2 --no-cpu --no-variants
-  traffic.json               HBM bytes per k_step launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of
-                             MI355X_MICROARCH.md, HBM section: FETCH_SIZE tallies 128-B requests at 64 B)
+  bench.json                 python bench.py (the full default run: headline workload, 2-D-gap variant, GP variant, cpu_baseline)
+  kernel_stats.csv           rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu
+  pmc_means_per_launch.json  per-kernel means of the counters, one rocprofv3 --pmc pass per group (never combined with other
+                             traces), python3 bench.py --steps 6 --warmup 2 --no-cpu --no-gp
+  traffic_line.json          HBM bytes per launch of the step kernel on the headline workload (x-only gap, topography read as
+  traffic_planes.json        a per-row profile) and on the 2-D-gap variant (three topography planes):
+                             2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of MI355X_MICROARCH.md, HBM section:
+                             FETCH_SIZE tallies 128-B requests at 64 B), separate --pmc passes
 
 The profiler is started as a child process with the interpreter right after `--` (no exec hops)."""
 import csv
@@ -31,48 +33,49 @@ def run(cmd, log, env=None):
 def main():
     out = os.path.abspath(sys.argv[1])
     env = dict(os.environ, TMPDIR='/tmp')
-    if '--planes' in sys.argv:
-        env['GPF_TOPO_PLANES'] = '1'
     os.makedirs(out, exist_ok=True)
     # 1. the benchmark line itself
     with open(os.path.join(out, 'bench.json'), 'w') as f:
         subprocess.run([sys.executable, 'bench.py'], stdout=f, stderr=open(os.path.join(out, 'bench.err'), 'w'), cwd=ROOT,
                        env=env, timeout=900, check=True)
-    # 2. kernel trace + stats of the same command (cpu leg and variant off: they add nothing to the kernel table)
+    print('bench.json written', flush=True)
+    # 2. kernel trace + stats of the same command (cpu leg off: it launches no kernels)
     kt = os.path.join(out, 'kt')
     run(['rocprofv3', '--kernel-trace', '--stats', '--output-format', 'csv', '-d', kt, '-o', 'kt', '--',
-         'python3', 'bench.py', '--no-cpu', '--no-variants'], os.path.join(out, 'kt.log'), env)
+         'python3', 'bench.py', '--no-cpu'], os.path.join(out, 'kt.log'), env)
     stats = glob.glob(os.path.join(kt, '**', '*kernel_stats.csv'), recursive=True)
     if stats:
         os.replace(stats[0], os.path.join(out, 'kernel_stats.csv'))
-    # 3. counters, one group per pass
+    # 3. counters, one group per pass; the headline workload runs the TOPO = 1 step kernel, the 2-D-gap variant TOPO = 0
     sums, counts = {}, {}
     for i, group in enumerate(PMC_PASSES):
         d = os.path.join(out, f'pmc{i}')
         run(['rocprofv3', '--pmc'] + group + ['--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'pmc', '--',
-             'python3', 'bench.py', '--steps', '6', '--warmup', '2', '--no-cpu', '--no-variants'],
+             'python3', 'bench.py', '--steps', '6', '--warmup', '2', '--no-cpu', '--no-gp'],
             os.path.join(out, f'pmc{i}.log'), env)
         for fn in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
             for row in csv.DictReader(open(fn)):
                 name = row['Kernel_Name'].split('(')[0].replace('void ', '')
                 key = (name, row['Counter_Name'])
                 sums[key] = sums.get(key, 0.0) + float(row['Counter_Value'])
-                counts[key] = counts.get(key, set())
-                counts[key].add(row['Dispatch_Id'])
+                counts.setdefault(key, set()).add(row['Dispatch_Id'])
+        print('pmc pass', i, 'done', flush=True)
     means = {}
     for (name, ctr), v in sums.items():
         means.setdefault(name, {})[ctr] = v / max(1, len(counts[(name, ctr)]))
     json.dump(means, open(os.path.join(out, 'pmc_means_per_launch.json'), 'w'), indent=1, sort_keys=True)
-    step = [k for k in means if 'k_step' in k]
-    if step and 'FETCH_SIZE' in means[step[0]] and 'WRITE_SIZE' in means[step[0]]:
-        m = means[step[0]]
-        traffic = {"kernel": step[0], "FETCH_SIZE_KB": m['FETCH_SIZE'], "WRITE_SIZE_KB": m['WRITE_SIZE'],
-                   "hbm_bytes_per_launch": (2 * m['FETCH_SIZE'] + m['WRITE_SIZE']) * 1024,
-                   "note": "gfx950 correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts 64 B per 128-B request "
-                           "-> doubled; WRITE_SIZE exact; separate --pmc passes, 4096^2 grid"
-                           + (", topography planes forced" if '--planes' in sys.argv else ", topography read as a per-row profile (x-only gap)")}
-        json.dump(traffic, open(os.path.join(out, 'traffic.json'), 'w'), indent=1)
-        print(json.dumps(traffic))
+    for kind, marker in (('line', ', 1>'), ('planes', ', 0>')):
+        step = [k for k in means if 'k_step2' in k and k.rstrip().endswith(marker)]
+        if step and 'FETCH_SIZE' in means[step[0]] and 'WRITE_SIZE' in means[step[0]]:
+            m = means[step[0]]
+            traffic = {"kernel": step[0], "FETCH_SIZE_KB": m['FETCH_SIZE'], "WRITE_SIZE_KB": m['WRITE_SIZE'],
+                       "hbm_bytes_per_launch": (2 * m['FETCH_SIZE'] + m['WRITE_SIZE']) * 1024,
+                       "note": "gfx950 correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts 64 B per 128-B request "
+                               "-> doubled; WRITE_SIZE exact; separate --pmc passes, 4096^2 grid, "
+                               + ("x-only gap: topography read as a per-row profile" if kind == 'line'
+                                  else "2-D gap (asperity, V = 0.05): three topography planes read")}
+            json.dump(traffic, open(os.path.join(out, f'traffic_{kind}.json'), 'w'), indent=1)
+            print(kind, json.dumps(traffic))
     # keep the directory small: raw traces are scratch
     for d in glob.glob(os.path.join(out, 'pmc[0-9]')) + [kt]:
         subprocess.run(['rm', '-rf', d])
