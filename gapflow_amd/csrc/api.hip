@@ -56,6 +56,7 @@ struct gpf_handle {
     double* topo = nullptr;                 // 3 planes
     double* topo_line = nullptr;            // [3][max(Nx,Ny)+2]: the profile when the topography varies along one axis only
     int topo_mode = 0;                      // 0: 2-D planes, 1: function of ix only, 2: function of iy only
+    bool topo_hy0 = false;                  // topo_mode 1 and dh/dy == 0 in every row
     double* Ls = nullptr;                   // 1 plane (allocated on first non-zero upload)
     double* g1 = nullptr;                   // g1x [3][pitch], g1y [3][Nx+2]: stage-1 ghost values of the step about to run
     double* seam = nullptr;                 // [2 edges][2 rows][4: h,hx,hy,Ls][pitch]
@@ -72,7 +73,7 @@ struct gpf_handle {
     long long p2p_timeout_ticks = P2P_TIMEOUT_TICKS;
     bool g1_ready = false;                  // g1 already holds the next step's stage-1 ghost values (k_begin_slab wrote them)
     Partial* block_partials = nullptr;      // one record per edge-kernel block
-    int npartials = 0, nstrips = 0, nchunks = 0, rows_per_chunk = 0, nghost_blocks = 0;
+    int nghost_blocks = 0;
     ScalarPartial* spart = nullptr;         // k_scalars block records (+ 4 totals at the end)
     int nspart = 0;
     LogEntry* log = nullptr;
@@ -106,8 +107,6 @@ struct gpf_handle {
     bool has_q = false, has_topo = false, pre_run_done = false;
     long long host_step = 0;                // step count at the last sync
     long long next_step = 0;                // index of the next step to be enqueued (== device step unless halted)
-    bool plan_valid = false;                // rows_per_chunk / nchunks fitted to the step kernel's residency
-    int max_chunks = 0;
     // two-columns-per-lane step kernel (step2_kernel.hip): window geometry per predictor direction [0: D=+1, 1: D=-1],
     // row chunks, grid; `fused`: ghost cells, stage-1 ghost data and the commit happen inside the kernel (no slab halo)
     Strip2Geom geom2[2];
@@ -205,12 +204,6 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
     h->E.halo[0] = cfg->halo_lo; h->E.halo[1] = cfg->halo_hi;
     make_phys(*cfg, h->P);
 
-    // strips of the fused step; the split of the rows into chunks is fitted to the kernel's residency
-    // on first use (plan_step), at most max_chunks of >= 2 rows
-    h->nstrips = (L.Ny + STRIP - 1) / STRIP;
-    h->max_chunks = std::max(1, (L.Nx + 1) / 2);
-    h->npartials = h->nstrips * h->max_chunks;
-
     const size_t plane_b = (size_t)L.plane * sizeof(double);
     auto cleanup = [&](int code) { gpf_destroy(h); return code; };
 #define HIP_TRY_C(expr)                                                                                 \
@@ -231,8 +224,6 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
     HIP_TRY_C(hipMalloc(&h->st, sizeof(StepState)));
     HIP_TRY_C(hipMemset(h->st, 0, sizeof(StepState)));
     h->nghost_blocks = std::max(1, std::min(64, (2 * (L.Ny + 2) + 2 * L.Nx + 255) / 256));
-    HIP_TRY_C(hipMalloc(&h->partials, (size_t)h->npartials * sizeof(Partial)));
-    HIP_TRY_C(hipMemset(h->partials, 0, (size_t)h->npartials * sizeof(Partial)));
     HIP_TRY_C(hipMalloc(&h->arrive, 4 * sizeof(unsigned int)));
     HIP_TRY_C(hipMemset(h->arrive, 0, 4 * sizeof(unsigned int)));
     HIP_TRY_C(hipMalloc(&h->block_partials, 1024 * sizeof(Partial)));
@@ -325,7 +316,7 @@ extern "C" int gpf_upload(gpf_handle* h, int field, const double* host, size_t c
         bool nz = false;
         for (size_t i = 0; i < count && !nz; ++i) nz = host[i] != 0.0;
         if (!nz && !h->Ls) return GPF_OK;      // Ls == 0 everywhere: the HAS_LS=false kernels apply
-        if (!h->Ls) { HIP_TRY(hipMalloc(&h->Ls, (size_t)L.plane * sizeof(double) + PLANE_PAD_BYTES)); h->plan_valid = false; h->plan2_valid = false; }
+        if (!h->Ls) { HIP_TRY(hipMalloc(&h->Ls, (size_t)L.plane * sizeof(double) + PLANE_PAD_BYTES)); h->plan2_valid = false; }
         HIP_TRY(hipMemsetAsync(h->Ls, 0, (size_t)L.plane * sizeof(double), h->stream));
         dst = h->Ls;
     }
@@ -343,7 +334,7 @@ extern "C" int gpf_upload(gpf_handle* h, int field, const double* host, size_t c
                 }
             }
         const int mode = xonly ? 1 : (yonly ? 2 : 0);
-        if (mode != h->topo_mode) { h->plan_valid = false; h->plan2_valid = false; }
+        if (mode != h->topo_mode) { h->plan2_valid = false; }
         h->topo_mode = h->el.on ? 0 : mode;         // an elastic gap changes on the device: always read the planes
         if (mode) {
             const int n = mode == 1 ? nx : ny;
@@ -351,6 +342,10 @@ extern "C" int gpf_upload(gpf_handle* h, int field, const double* host, size_t c
             for (int c = 0; c < 3; ++c)
                 for (int i = 0; i < n; ++i)
                     line[(size_t)c * n + i] = mode == 1 ? host[((size_t)c * nx + i) * ny] : host[(size_t)c * nx * ny + i];
+            bool hy0 = mode == 1;
+            for (int i = 0; i < n && hy0; ++i) hy0 = line[(size_t)2 * n + i] == 0.0;
+            if (hy0 != h->topo_hy0) h->plan2_valid = false;
+            h->topo_hy0 = hy0;
             if (!h->topo_line) HIP_TRY(hipMalloc(&h->topo_line, (size_t)3 * (std::max(nx, ny)) * sizeof(double)));
             HIP_TRY(hipMemcpy(h->topo_line, line.data(), line.size() * sizeof(double), hipMemcpyHostToDevice));
         }
@@ -557,56 +552,13 @@ extern "C" int gpf_pre_run(gpf_handle* h) {
 // ---------------------------------------------------------------------------------------------
 // the fused step
 // ---------------------------------------------------------------------------------------------
-typedef void (*step_kernel_t)(const StepArgs, const Phys);
-
-// topo_mode: 0 planes, 1 profile over ix, 2 profile over iy (only without slip-length field / piezo-viscosity)
-static step_kernel_t step_kernel(int eos, bool has_ls, bool piezo, int D, int topo_mode) {
-    step_kernel_t k = nullptr;
-    EOS_DISPATCH(eos, {
-        if (piezo) {
-            if (has_ls) k = D > 0 ? k_step<EOS_, true, true, 1, 0> : k_step<EOS_, true, true, -1, 0>;
-            else k = D > 0 ? k_step<EOS_, false, true, 1, 0> : k_step<EOS_, false, true, -1, 0>;
-        } else if (has_ls) {
-            k = D > 0 ? k_step<EOS_, true, false, 1, 0> : k_step<EOS_, true, false, -1, 0>;
-        } else if (topo_mode == 1) {
-            k = D > 0 ? k_step<EOS_, false, false, 1, 1> : k_step<EOS_, false, false, -1, 1>;
-        } else if (topo_mode == 2) {
-            k = D > 0 ? k_step<EOS_, false, false, 1, 2> : k_step<EOS_, false, false, -1, 2>;
-        } else {
-            k = D > 0 ? k_step<EOS_, false, false, 1, 0> : k_step<EOS_, false, false, -1, 0>;
-        }
-    });
-    return k;
-}
-
+// 0 planes, 1 profile over ix, 2 profile over iy, 3 profile over ix with dh/dy = 0 (the x-only-gap closure); the line
+// modes only without slip-length field / piezo-viscosity.  GPF_TOPO_PLANES / GPF_TOPO_GENERIC switch the specialisations
+// off for A/B runs.
 static int topo_mode_of(const gpf_handle* h) {
     if (h->Ls != nullptr || h->cfg.piezo != 0 || std::getenv("GPF_TOPO_PLANES")) return 0;
+    if (h->topo_mode == 1 && h->topo_hy0 && !std::getenv("GPF_TOPO_GENERIC")) return 3;
     return h->topo_mode;
-}
-
-// One wave marches over `rows_per_chunk` rows of one strip.  The chunks are sized so that the whole
-// grid is resident at once (a single round of waves, no tail) when the problem is big enough.
-static int plan_step(gpf_handle* h) {
-    if (h->plan_valid) return GPF_OK;
-    const Layout& L = h->L;
-    int rows = 0;
-    if (const char* s = std::getenv("GPF_ROWS_PER_CHUNK")) rows = std::atoi(s);
-    if (rows <= 0) {
-        int per_cu = 0, ncu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)step_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, 1, topo_mode_of(h)), 256, 0));
-        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->cfg.device));
-        const int blocks_per_chunk = (h->nstrips + 3) / 4;
-        const int resident = std::max(1, per_cu * ncu);
-        const int want_chunks = std::max(1, resident / blocks_per_chunk);
-        rows = (L.Nx + want_chunks - 1) / want_chunks;
-    }
-    rows = std::max(4, std::min(rows, L.Nx));       // small grids: short chunks spread the rows over more CUs (256^2: 13.7 -> 10.8 us)
-    if (rows > L.Nx) rows = L.Nx;
-    h->rows_per_chunk = std::min(rows, std::max(L.Nx, 1));
-    h->nchunks = (L.Nx + h->rows_per_chunk - 1) / h->rows_per_chunk;
-    if (h->nchunks > h->max_chunks) return fail(GPF_ERR_INVALID, "plan_step: chunk count exceeds the partials buffer");
-    h->plan_valid = true;
-    return GPF_OK;
 }
 
 // ---- two-columns-per-lane step kernel (step2_kernel.hip) ----
@@ -624,6 +576,8 @@ static step2_kernel_t step2_kernel(int eos, bool has_ls, bool piezo, int D, int 
             k = D > 0 ? k_step2<EOS_, false, false, 1, 1> : k_step2<EOS_, false, false, -1, 1>;
         } else if (topo_mode == 2) {
             k = D > 0 ? k_step2<EOS_, false, false, 1, 2> : k_step2<EOS_, false, false, -1, 2>;
+        } else if (topo_mode == 3) {
+            k = D > 0 ? k_step2<EOS_, false, false, 1, 3> : k_step2<EOS_, false, false, -1, 3>;
         } else {
             k = D > 0 ? k_step2<EOS_, false, false, 1, 0> : k_step2<EOS_, false, false, -1, 0>;
         }
@@ -655,10 +609,6 @@ static Strip2Geom strip2_geom(const Layout& L, int D) {
     return G;
 }
 
-static bool use_step2() {
-    static const bool off = std::getenv("GPF_STEP_KERNEL") && std::atoi(std::getenv("GPF_STEP_KERNEL")) == 1;
-    return !off;
-}
 // ghost cells, stage-1 ghost data and the commit inside k_step2: every handle that is not a slab
 static bool step2_fused(const gpf_handle* h) {
     static const bool off = std::getenv("GPF_STEP_UNFUSED_EDGES") != nullptr;
@@ -691,7 +641,7 @@ static int plan_step2(gpf_handle* h) {
         h->partials = nullptr;
         HIP_TRY(hipMalloc(&h->partials, (size_t)nwaves * sizeof(Partial)));
         HIP_TRY(hipMemset(h->partials, 0, (size_t)nwaves * sizeof(Partial)));
-        h->npartials2_cap = nwaves; h->npartials = std::max(h->npartials, nwaves);
+        h->npartials2_cap = nwaves;
     }
     if (h->nblocks2 > h->nblock_partials_cap) {
         const int cap = std::max(1024, h->nblocks2);
@@ -730,26 +680,19 @@ static int ghost_args(gpf_handle* h, int honor_stop, GhostArgs& g) {
 static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, double* slab_out,
                         hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, bool p2p = false) {
     const Layout& L = h->L;
-    const bool two = use_step2();
-    if (two) GPF_TRY(plan_step2(h));
-    else GPF_TRY(plan_step(h));
+    GPF_TRY(plan_step2(h));
     const int mc = h->cfg.mc_order;
     const int D = mc == 0 ? ((h->next_step % 2 == 0) ? 1 : -1) : (((mc + 1) / 2) ? 1 : -1);
     h->next_step += 1;
-    const bool fused = two && step2_fused(h) && slab_out == nullptr && !p2p;
+    const bool fused = step2_fused(h) && slab_out == nullptr && !p2p;
     const Strip2Geom& G2 = h->geom2[D > 0 ? 0 : 1];
-    const int np_step = two ? G2.nstrips * h->nchunks2 : h->nstrips * h->nchunks;
+    const int np_step = G2.nstrips * h->nchunks2;
     Step2Args a2;
     a2.qa = h->q[0]; a2.qb = h->q[1]; a2.topo = h->topo; a2.topo_line = h->topo_line; a2.Ls = h->Ls;
     a2.g1x = h->g1; a2.g1y = h->g1 + 3 * L.pitch;
     a2.st = h->st; a2.partials = h->partials; a2.block_partials = h->block_partials; a2.arrive = h->arrive;
     a2.log = h->log; a2.log_base = log_base; a2.log_cap = h->log_cap;
     a2.L = L; a2.E = h->E; a2.G = G2; a2.nchunks = h->nchunks2; a2.fused = fused ? 1 : 0; a2.honor_stop = honor_stop;
-    StepArgs a;
-    a.qa = h->q[0]; a.qb = h->q[1]; a.topo = h->topo; a.topo_line = h->topo_line; a.Ls = h->Ls;
-    a.g1x = h->g1; a.g1y = h->g1 + 3 * L.pitch;
-    a.st = h->st; a.partials = h->partials; a.L = L; a.E = h->E;
-    a.rows_per_chunk = h->rows_per_chunk; a.nstrips = h->nstrips; a.honor_stop = honor_stop;
     GhostArgs g;
     GPF_TRY(ghost_args(h, honor_stop, g));
     const bool slab = slab_out != nullptr;
@@ -764,16 +707,16 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     gf.qa = h->q[0]; gf.qb = h->q[1]; gf.st = h->st;
     gf.L = L; gf.E = h->E; gf.honor_stop = honor_stop;
 
-    // Launches per step:
+    // Launches per step.  A handle that is not a slab: k_step2 alone (ghost cells, stage-1 ghost data, reductions and the
+    // commit happen inside it).  A slab:
     //   k_ghost_stage1  stage-1 values on the downwind ghost row / column (needs the dt the previous step committed)
-    //   k_step          the fused predictor + corrector + average over the interior
-    //   k_ghost_fill    ghost cells of the new field (+ a slab's boundary rows into its message / its peers'
-    //                   mailboxes); its last block to finish reduces all records and commits dt, residual, step
-    //   peer-to-peer slabs: k_begin_slab (wait for the peers' rows and records, commit, k_ghost_stage1's job for the
-    //                   next step) takes the place of the next step's k_ghost_stage1
+    //   k_step2         the fused predictor + corrector + average over the interior
+    //   k_ghost_fill    ghost cells of the new field + the slab's boundary rows into its message / its peers' mailboxes;
+    //                   its last block to finish reduces all records into this rank's record
+    //   k_begin_slab    (after the exchange) scatter the neighbours' rows, rank-ordered reduction, commit, and
+    //                   k_ghost_stage1's job for the next step
     const int ntiles = (L.Nx + L.Ny + 63) / 64;                 // stage-1 ghost work: 64 items per block
-    const dim3 ggrid(std::min(ntiles, 512)), sgrid((h->nstrips + 3) / 4, std::max(1, h->nchunks));
-    const step_kernel_t kstep = step_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, D, topo_mode_of(h));
+    const dim3 ggrid(std::min(ntiles, 512));
     const int nsend = slab ? std::min((6 * L.pitch + 1023) / 1024, 256) : 0;        // block_partials holds 1024
     WaitArgs w;
     w.qa = h->q[0]; w.qb = h->q[1]; w.st = h->st; w.log = h->log; w.log_base = log_base; w.log_cap = h->log_cap;
@@ -792,19 +735,16 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     }
     EOS_DISPATCH(h->cfg.eos, {
         if (!h->g1_ready) {
-            LS_PIEZO_DISPATCH(has_ls, h->cfg.piezo != 0, hipLaunchKernelGGL((k_ghost_stage1<EOS_, LS_, PZ_>), ggrid, dim3(256), 0, h->stream, g, h->P));
+            if (topo_mode_of(h) == 3) hipLaunchKernelGGL((k_ghost_stage1<EOS_, false, false, true>), ggrid, dim3(256), 0, h->stream, g, h->P);
+            else LS_PIEZO_DISPATCH(has_ls, h->cfg.piezo != 0, hipLaunchKernelGGL((k_ghost_stage1<EOS_, LS_, PZ_, false>), ggrid, dim3(256), 0, h->stream, g, h->P));
         }
         if (ev0) hipEventRecord(ev0, h->stream);
-        if (two) {
-            const step2_kernel_t k2 = step2_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, D, topo_mode_of(h));
-            hipLaunchKernelGGL(k2, dim3(h->nblocks2), dim3(256), 0, h->stream, a2, h->P);
-        } else {
-            hipLaunchKernelGGL(kstep, sgrid, dim3(256), 0, h->stream, a, h->P);
-        }
+        hipLaunchKernelGGL(step2_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, D, topo_mode_of(h)), dim3(h->nblocks2), dim3(256), 0, h->stream, a2, h->P);
         if (ev1) hipEventRecord(ev1, h->stream);
         hipLaunchKernelGGL((k_ghost_fill<EOS_>), dim3(h->nghost_blocks + nsend), dim3(256), 0, h->stream, gf, f, h->nghost_blocks, h->P);
         if (p2p) {                          // wait for the peers, commit, stage-1 ghost data of the next step
-            LS_PIEZO_DISPATCH(has_ls, h->cfg.piezo != 0, hipLaunchKernelGGL((k_begin_slab<EOS_, LS_, PZ_, true>), ggrid, dim3(256), 0, h->stream, g, w, h->P));
+            if (topo_mode_of(h) == 3) hipLaunchKernelGGL((k_begin_slab<EOS_, false, false, true, true>), ggrid, dim3(256), 0, h->stream, g, w, h->P);
+            else LS_PIEZO_DISPATCH(has_ls, h->cfg.piezo != 0, hipLaunchKernelGGL((k_begin_slab<EOS_, LS_, PZ_, false, true>), ggrid, dim3(256), 0, h->stream, g, w, h->P));
         }
     });
     h->g1_ready = p2p;                  // k_begin_slab has prepared the next step's ghost data

@@ -515,7 +515,7 @@ struct WaitArgs {
 };
 // MAILBOX: rows and records are waited for in this rank's mailbox (peer-to-peer transport); otherwise they are read from
 // the buffer an all-gather has filled before this launch (same layout as gpf_slab_message, rank order).
-template <int EOS, bool HAS_LS, bool PIEZO, bool MAILBOX>
+template <int EOS, bool HAS_LS, bool PIEZO, bool XONLY, bool MAILBOX>
 __global__ __launch_bounds__(256) void k_begin_slab(const GhostArgs g, const WaitArgs a, const Phys P) {
     __shared__ int missing, last;
     __shared__ double tiles[2][3][64];
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void k_begin_slab(const GhostArgs g, const Wai
         MailField fld;
         fld.q = q; fld.L = L; fld.row_lo = row_lo; fld.row_hi = row_hi;
         const int ntiles = (L.Ny + L.Nx + 63) / 64;
-        for (int tile = block; tile < ntiles; tile += nblocks) ghost_stage1_tile<EOS, HAS_LS, PIEZO>(fld, g, P, D, tile * 64, dt, tiles);
+        for (int tile = block; tile < ntiles; tile += nblocks) ghost_stage1_tile<EOS, HAS_LS, PIEZO, XONLY>(fld, g, P, D, tile * 64, dt, tiles);
     }
     // the last block to get here writes the committed state (the others have read everything they need from it)
     __syncthreads();

@@ -350,6 +350,97 @@ GPF_HD void cell_closure(const CellIn& c, const Phys& P, CellFlux& o) {
     cell_closure<EOS, WITH_SOURCE, HAS_LS, PIEZO>(c, topo_rcp<HAS_LS>(c), P, o);
 }
 
+// ---- no slip-length field, constant viscosity (the common case): D = h ----------------------------------------------
+// With Ls = 0 the polynomials of viscous.py's slip-top branch lose their h-dependence up to the slopes per gap height
+// a = hx/h, b = hy/h, and everything is linear in the velocities m = j / rho:
+//   tau_xx = v1 a m_x + v2 b m_y        tau_yy = v2 a m_x + v1 b m_y        tau_xy = eta (b m_x + a m_y)
+//   tau - tau^top:  d_xx = v1 a P_x + v2 b P_y,  d_yy = v2 a P_x + v1 b P_y,  d_xy = eta (b P_x + a P_y),  P = 2 W - 5 m
+//   tau_xz^top - tau_xz^bot = -2 eta (6 m_x - 3 U)/h                         (yz alike)
+//   s0 = -(a jx + b jy),   s1 = d_xx a + d_xy b - E (6 m_x - 3 U),   s2 = d_xy a + d_yy b - E (6 m_y - 3 V),   E = 2 eta/h^2
+// -- the same rational functions as cell_closure<.., HAS_LS = false, PIEZO = false> (tests/hostcheck compares the two)
+// in two thirds of the arithmetic; a, b and 1/h are formed once per cell and step and serve both stages.
+struct GapCoef { double ih, a, b; };
+
+GPF_HD GapCoef gap_coefficients(double h, double hx, double hy) {
+    GapCoef g;
+    g.ih = rcp(h);
+    g.a = hx * g.ih;
+    g.b = hy * g.ih;
+    return g;
+}
+
+template <int EOS>
+GPF_HD void cell_closure_ls0(double rho, double jx, double jy, const GapCoef& g, const Phys& P, CellFlux& o) {
+#ifdef GPF_STUB_CLOSURE     // diagnostic build: memory-access pattern of the step without its arithmetic
+    o.p = rho; o.fx1 = rho + g.ih; o.fx2 = jx + g.a; o.fy2 = jy + g.b; o.s0 = g.ih; o.s1 = g.a; o.s2 = g.b;
+    return;
+#endif
+    const double p = eos_pressure<EOS>(rho, P);
+    const double ir = rcp(rho);
+    const double mx = jx * ir, my = jy * ir;
+    const double ax = g.a * mx, by = g.b * my;
+    const double txx = fma(P.v1, ax, P.v2 * by);
+    const double tyy = fma(P.v2, ax, P.v1 * by);
+    const double txy = P.eta * fma(g.b, mx, g.a * my);
+    o.p = p;
+    o.fx1 = p + txx;
+    o.fx2 = txy;
+    o.fy2 = p + tyy;
+    const double px = fma(-5.0, mx, 2.0 * P.U), py = fma(-5.0, my, 2.0 * P.V);
+    const double apx = g.a * px, bpy = g.b * py;
+    const double dxx = fma(P.v1, apx, P.v2 * bpy);
+    const double dyy = fma(P.v2, apx, P.v1 * bpy);
+    const double dxy = P.eta * fma(g.b, px, g.a * py);
+    const double E = (2.0 * P.eta) * (g.ih * g.ih);
+    const double wx = fma(6.0, mx, -3.0 * P.U), wy = fma(6.0, my, -3.0 * P.V);
+    o.s0 = -fma(g.a, jx, g.b * jy);
+    o.s1 = fma(dxx, g.a, fma(dxy, g.b, -(E * wx)));
+    o.s2 = fma(dxy, g.a, fma(dyy, g.b, -(E * wy)));
+}
+
+// ---- gaps that vary along x only: h = h(x), dh/dy = 0, no slip-length field, constant viscosity -----------------
+// journal, inclined, parabolic and cdc profiles (topography.py:57-130).  With D = h and hy = 0 every stress of
+// viscous.py's slip-top branch is LINEAR in the velocities m = j / rho, with coefficients that depend on the row only:
+//   tau_xx = A m_x,  tau_yy = B m_x,  tau_xy = C m_y          A = v1 hx/h, B = v2 hx/h, C = eta hx/h
+//   tau_xx^top = 2A (3 m_x - U),  tau_xy^top = 2C (3 m_y - V)
+//   tau_xz^top = -2 eta (3 m_x - U)/h,  tau_xz^bot = 2 eta (3 m_x - 2U)/h          (yz alike with m_y, V)
+//   s0 = -(hx/h) jx
+//   s1 = [(tau_xx - tau_xx^top) hx + tau_xz^top - tau_xz^bot]/h = -(5 A hx/h + 12 eta/h^2) m_x + U (2 A hx/h + 6 eta/h^2)
+//   s2 = [(tau_xy - tau_xy^top) hx + tau_yz^top - tau_yz^bot]/h = -(5 C hx/h + 12 eta/h^2) m_y + V (2 C hx/h + 6 eta/h^2)
+// -- the same rational functions as cell_closure with hy = Ls = 0 (tests/hostcheck compares the two), a third of the
+// arithmetic.  The contractions are spelled out so that every kernel rounds alike.
+struct RowCoef { double A, B, C, S0, S1a, S1b, S2a, S2b; };
+
+GPF_HD RowCoef row_coefficients(double h, double hx, const Phys& P) {
+    const double ih = rcp(h);
+    const double g = hx * ih;
+    const double e = P.eta * (ih * ih);
+    RowCoef r;
+    r.A = P.v1 * g; r.B = P.v2 * g; r.C = P.eta * g; r.S0 = -g;
+    const double Ag = r.A * g, Cg = r.C * g;
+    r.S1a = fma(-5.0, Ag, -12.0 * e); r.S1b = P.U * fma(2.0, Ag, 6.0 * e);
+    r.S2a = fma(-5.0, Cg, -12.0 * e); r.S2b = P.V * fma(2.0, Cg, 6.0 * e);
+    return r;
+}
+
+template <int EOS>
+GPF_HD void cell_closure_xonly(double rho, double jx, double jy, const RowCoef& r, const Phys& P, CellFlux& o) {
+#ifdef GPF_STUB_CLOSURE
+    o.p = rho; o.fx1 = rho + r.A; o.fx2 = jx + r.C; o.fy2 = jy + r.B; o.s0 = r.S0; o.s1 = r.S1a; o.s2 = r.S2a;
+    return;
+#endif
+    const double p = eos_pressure<EOS>(rho, P);
+    const double ir = rcp(rho);
+    const double mx = jx * ir, my = jy * ir;
+    o.p = p;
+    o.fx1 = fma(r.A, mx, p);
+    o.fx2 = r.C * my;
+    o.fy2 = fma(r.B, mx, p);
+    o.s0 = r.S0 * jx;
+    o.s1 = fma(r.S1a, mx, r.S1b);
+    o.s2 = fma(r.S2a, my, r.S2b);
+}
+
 // The full set of derived fields the reference keeps per cell (for gpf_update_closures).
 struct CellFields {
     double p;

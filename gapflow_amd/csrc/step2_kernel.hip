@@ -127,7 +127,7 @@ struct RawRow {
     dpair q[3];
     dpair t[TOPO == 0 ? 3 : 1];     // h, hx, hy planes (TOPO = 0 only)
     dpair ls[HAS_LS ? 1 : 1];
-    double th, thx, thy;            // TOPO = 1: the row's (h, hx, hy), wave-uniform
+    double th, thx, thy;            // TOPO = 1, 3: the row's (h, hx, hy), wave-uniform
 };
 
 // two adjacent cells of one row, as one lane holds them
@@ -204,8 +204,10 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
     double* __restrict__ qo1 = qout + L.plane;
     double* __restrict__ qo2 = qout + 2 * L.plane;
 
-    // TOPO as in step_kernel.hip: 1 = one (h, hx, hy) triple per ROW through the scalar cache, 2 = the lane's two
-    // column triples stay in registers for the whole march; the values are bitwise those of the planes.
+    // TOPO: most gap profiles vary along one axis only (journal, inclined, parabolic, cdc: h = h(x)); a third of the
+    // step's HBM reads is then redundant.  1 = one (h, hx, hy) triple per ROW through the scalar cache, 2 = the lane's
+    // two column triples stay in registers for the whole march (flipped geometries); the values are bitwise those of
+    // the planes.  3 = as 1 with dh/dy = 0 throughout: the x-only-gap closure (closures.hpp, cell_closure_xonly).
     double lh[2] = {0.0, 0.0}, lhx[2] = {0.0, 0.0}, lhy[2] = {0.0, 0.0};
     if (TOPO == 2) {
         const int c0 = min(max(iy0, 0), L.Ny + 1), c1 = min(max(iy1, 0), L.Ny + 1);
@@ -225,8 +227,8 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
         pair(q0p + rb, r.rho[0], r.rho[1]); pair(q1p + rb, r.jx[0], r.jx[1]); pair(q2p + rb, r.jy[0], r.jy[1]);
         if (TOPO == 0) {
             pair(hp + rb, r.h[0], r.h[1]); pair(hxp + rb, r.hx[0], r.hx[1]); pair(hyp + rb, r.hy[0], r.hy[1]);
-        } else if (TOPO == 1) {
-            const double th = a.topo_line[ix], thx = a.topo_line[(L.Nx + 2) + ix], thy = a.topo_line[2 * (L.Nx + 2) + ix];
+        } else if (TOPO == 1 || TOPO == 3) {
+            const double th = a.topo_line[ix], thx = a.topo_line[(L.Nx + 2) + ix], thy = TOPO == 1 ? a.topo_line[2 * (L.Nx + 2) + ix] : 0.0;
             r.h[0] = r.h[1] = th; r.hx[0] = r.hx[1] = thx; r.hy[0] = r.hy[1] = thy;
         } else {
             r.h[0] = lh[0]; r.h[1] = lh[1]; r.hx[0] = lhx[0]; r.hx[1] = lhx[1]; r.hy[0] = lhy[0]; r.hy[1] = lhy[1];
@@ -235,7 +237,7 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
         else r.Ls[0] = r.Ls[1] = 0.0;
     };
     // ---- the pipelined row loads of the march ----
-    constexpr int NL = 3 + (TOPO == 0 ? 3 : 0) + (HAS_LS ? 1 : 0);       // vector loads per row
+    constexpr int NL = 3 + (TOPO == 0 ? 3 : 0) + (HAS_LS ? 1 : 0);       // vector loads per row (TOPO 1, 3: the gap travels as scalars)
     typedef RawRow<TOPO, HAS_LS> Raw;
     const double* const lane_q = reinterpret_cast<const double*>(reinterpret_cast<const char*>(qin) + lane_bytes);
     const double* const lane_t = reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.topo) + lane_bytes);
@@ -246,8 +248,9 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
         asm_load16(r.q[0], lane_q + rb); asm_load16(r.q[1], lane_q + L.plane + rb); asm_load16(r.q[2], lane_q + 2 * L.plane + rb);
         if (TOPO == 0) {
             asm_load16(r.t[0], lane_t + rb); asm_load16(r.t[1], lane_t + L.plane + rb); asm_load16(r.t[2], lane_t + 2 * L.plane + rb);
-        } else if (TOPO == 1) {
-            r.th = uniform_load(a.topo_line + ix); r.thx = uniform_load(a.topo_line + (L.Nx + 2) + ix); r.thy = uniform_load(a.topo_line + 2 * (L.Nx + 2) + ix);
+        } else if (TOPO == 1 || TOPO == 3) {
+            r.th = uniform_load(a.topo_line + ix); r.thx = uniform_load(a.topo_line + (L.Nx + 2) + ix);
+            r.thy = TOPO == 1 ? uniform_load(a.topo_line + 2 * (L.Nx + 2) + ix) : 0.0;
         }
         if (HAS_LS) asm_load16(r.ls[0], lane_ls + rb);
     };
@@ -265,13 +268,28 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
             o.h[0] = D > 0 ? r.t[0].x : r.t[0].y; o.h[1] = D > 0 ? r.t[0].y : r.t[0].x;
             o.hx[0] = D > 0 ? r.t[1].x : r.t[1].y; o.hx[1] = D > 0 ? r.t[1].y : r.t[1].x;
             o.hy[0] = D > 0 ? r.t[2].x : r.t[2].y; o.hy[1] = D > 0 ? r.t[2].y : r.t[2].x;
-        } else if (TOPO == 1) {
+        } else if (TOPO == 1 || TOPO == 3) {
             o.h[0] = o.h[1] = r.th; o.hx[0] = o.hx[1] = r.thx; o.hy[0] = o.hy[1] = r.thy;
         } else {
             o.h[0] = lh[0]; o.h[1] = lh[1]; o.hx[0] = lhx[0]; o.hx[1] = lhx[1]; o.hy[0] = lhy[0]; o.hy[1] = lhy[1];
         }
         if (HAS_LS) { o.Ls[0] = D > 0 ? r.ls[0].x : r.ls[0].y; o.Ls[1] = D > 0 ? r.ls[0].y : r.ls[0].x; }
         else o.Ls[0] = o.Ls[1] = 0.0;
+    };
+    // the closure of slot k of row r (its density and fluxes possibly replaced by a stage-1 state q)
+    // Three forms of one closure: the x-only-gap form (TOPO = 3), the Ls = 0 / constant-viscosity form, the general one.
+    constexpr bool LS0 = !HAS_LS && !PIEZO;
+    auto closure = [&](const Row2& r, int k, const double* q, const TopoRcp& t, const GapCoef& gc, const RowCoef& rc, CellFlux& f) {
+        if (TOPO == 3) {
+            cell_closure_xonly<EOS>(q ? q[0] : r.rho[k], q ? q[1] : r.jx[k], q ? q[2] : r.jy[k], rc, P, f);
+        } else if (LS0) {
+            cell_closure_ls0<EOS>(q ? q[0] : r.rho[k], q ? q[1] : r.jx[k], q ? q[2] : r.jy[k], gc, P, f);
+        } else {
+            CellIn c;
+            c.rho = q ? q[0] : r.rho[k]; c.jx = q ? q[1] : r.jx[k]; c.jy = q ? q[2] : r.jy[k];
+            c.h = r.h[k]; c.hx = r.hx[k]; c.hy = r.hy[k]; c.Ls = r.Ls[k];
+            cell_closure<EOS, true, HAS_LS, PIEZO>(c, t, P, f);
+        }
     };
     auto cell_of = [&](const Row2& r, int k) {
         CellIn c;
@@ -291,9 +309,11 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
         load(1, r1);
         double fy[2][3], q1[2][3];
         CellFlux f0[2], f1[2];
+        const RowCoef rc0 = TOPO == 3 ? row_coefficients(r0.h[0], r0.hx[0], P) : RowCoef();
+        const RowCoef rc1 = TOPO == 3 ? row_coefficients(r1.h[0], r1.hx[0], P) : RowCoef();
         for (int k = 0; k < 2; ++k) {
-            cell_closure<EOS, false, HAS_LS, PIEZO>(cell_of(r0, k), P, f0[k]);
-            cell_closure<EOS, true, HAS_LS, PIEZO>(cell_of(r1, k), P, f1[k]);
+            closure(r0, k, nullptr, topo_rcp<HAS_LS>(cell_of(r0, k)), gap_coefficients(r0.h[k], r0.hx[k], r0.hy[k]), rc0, f0[k]);
+            closure(r1, k, nullptr, topo_rcp<HAS_LS>(cell_of(r1, k)), gap_coefficients(r1.h[k], r1.hx[k], r1.hy[k]), rc1, f1[k]);
             fy[k][0] = r1.jy[k]; fy[k][1] = f1[k].fx2; fy[k][2] = f1[k].fy2;
         }
         const double u0 = lane_from_below(fy[1][0]), u1 = lane_from_below(fy[1][1]), u2 = lane_from_below(fy[1][2]);
@@ -342,9 +362,18 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
         const bool last = (n == n_last + 1);
         const int ix = D > 0 ? n : L.Nx + 1 - n;
 
-        TopoRcp tr[2];
-        tr[0] = topo_rcp<HAS_LS>(cell_of(cur, 0));
-        tr[1] = topo_rcp<HAS_LS>(cell_of(cur, 1));
+        TopoRcp tr[2] = {TopoRcp(), TopoRcp()};
+        GapCoef gc[2] = {GapCoef(), GapCoef()};
+        RowCoef rc = RowCoef();
+        if (TOPO == 3) {
+            rc = row_coefficients(cur.h[0], cur.hx[0], P);      // one set per row: the gap is the same in every column
+        } else if (LS0) {
+            gc[0] = gap_coefficients(cur.h[0], cur.hx[0], cur.hy[0]);   // once per cell and step: both stages use them
+            gc[1] = gap_coefficients(cur.h[1], cur.hx[1], cur.hy[1]);
+        } else {
+            tr[0] = topo_rcp<HAS_LS>(cell_of(cur, 0));
+            tr[1] = topo_rcp<HAS_LS>(cell_of(cur, 1));
+        }
 
         // ---- stage 1 at (n, m) ----
         double q1[2][3];
@@ -355,7 +384,7 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
             CellFlux f[2];
             double fy[2][3];
             for (int k = 0; k < 2; ++k) {
-                cell_closure<EOS, true, HAS_LS, PIEZO>(cell_of(cur, k), tr[k], P, f[k]);
+                closure(cur, k, nullptr, tr[k], gc[k], rc, f[k]);
                 fy[k][0] = cur.jy[k]; fy[k][1] = f[k].fx2; fy[k][2] = f[k].fy2;
             }
             const double u0 = lane_from_below(fy[1][0]), u1 = lane_from_below(fy[1][1]), u2 = lane_from_below(fy[1][2]);
@@ -396,9 +425,7 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
             CellFlux g[2];
             double gy[2][3];
             for (int k = 0; k < 2; ++k) {
-                CellIn c1 = cell_of(cur, k);
-                c1.rho = q1[k][0]; c1.jx = q1[k][1]; c1.jy = q1[k][2];
-                cell_closure<EOS, true, HAS_LS, PIEZO>(c1, tr[k], P, g[k]);
+                closure(cur, k, q1[k], tr[k], gc[k], rc, g[k]);
                 gy[k][0] = q1[k][2]; gy[k][1] = g[k].fx2; gy[k][2] = g[k].fy2;
             }
             const double d0 = lane_from_above(gy[0][0]), d1 = lane_from_above(gy[0][1]), d2 = lane_from_above(gy[0][2]);
@@ -526,7 +553,7 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
 // device-side step counter.  Grid: gridDim.x = a multiple of 8 blocks of 4 waves; wave w of the XCD-ordered numbering
 // works on strip w % nstrips of chunk w / nstrips.
 template <int EOS, bool HAS_LS, bool PIEZO, int D, int TOPO>
-__global__ __launch_bounds__(256, (TOPO == 1 ? GPF_K2_MINWAVES_LINE : GPF_K2_MINWAVES)) void k_step2(const Step2Args a, const Phys P) {
+__global__ __launch_bounds__(256, ((TOPO == 1 || TOPO == 3) ? GPF_K2_MINWAVES_LINE : GPF_K2_MINWAVES)) void k_step2(const Step2Args a, const Phys P) {
     __shared__ double stash[4][3][128];         // per wave: stage-1 field on the downwind ghost row (fused)
     __shared__ Acc red_sm[4];
     __shared__ int s_last;

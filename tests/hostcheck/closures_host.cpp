@@ -75,6 +75,39 @@ int main() {
             d = std::fmax(d, rel(g.s0, s0, s0));
             d = std::fmax(d, rel(g.s1, s1, sc));
             d = std::fmax(d, rel(g.s2, s2, sc));
+            // the x-only-gap closure against the general one on the same cell with hy = Ls = 0
+            {
+                CellIn cx = c;
+                cx.hy = 0.0; cx.Ls = 0.0;
+                CellFlux a, b;
+                cell_closure<EOS_DH, true, false, false>(cx, P, a);
+                cell_closure_xonly<EOS_DH>(cx.rho, cx.jx, cx.jy, row_coefficients(cx.h, cx.hx, P), P, b);
+                const double ss = std::fabs(a.s1) + std::fabs(a.s2) + 1e-300;
+                d = std::fmax(d, rel(b.fx1, a.fx1, a.fx1));
+                d = std::fmax(d, rel(b.fx2, a.fx2, std::fabs(a.fx2) + std::fabs(a.fx1 - a.p) + 1e-300));
+                d = std::fmax(d, rel(b.fy2, a.fy2, a.fy2));
+                d = std::fmax(d, rel(b.s0, a.s0, a.s0));
+                d = std::fmax(d, rel(b.s1, a.s1, ss));
+                d = std::fmax(d, rel(b.s2, a.s2, ss));
+            }
+            // the Ls = 0 closure against the general one on the same cell with Ls = 0 (hx, hy as they are)
+            {
+                CellIn c0 = c;
+                c0.Ls = 0.0;
+                CellFlux a, b;
+                cell_closure<EOS_DH, true, false, false>(c0, P, a);
+                cell_closure_ls0<EOS_DH>(c0.rho, c0.jx, c0.jy, gap_coefficients(c0.h, c0.hx, c0.hy), P, b);
+                const double ss = std::fabs(a.s1) + std::fabs(a.s2) + 1e-300;
+                const double ts = std::fabs(a.fx2) + std::fabs(a.fx1 - a.p) + std::fabs(a.fy2 - a.p) + 1e-300;
+                d = std::fmax(d, rel(b.fx1, a.fx1, a.fx1));
+                d = std::fmax(d, rel(b.fx2, a.fx2, ts));
+                d = std::fmax(d, rel(b.fy2, a.fy2, a.fy2));
+                d = std::fmax(d, rel(b.fx1 - b.p, a.fx1 - a.p, ts));
+                d = std::fmax(d, rel(b.fy2 - b.p, a.fy2 - a.p, ts));
+                d = std::fmax(d, rel(b.s0, a.s0, std::fabs(c0.jx * c0.hx / c0.h) + std::fabs(c0.jy * c0.hy / c0.h)));
+                d = std::fmax(d, rel(b.s1, a.s1, ss));
+                d = std::fmax(d, rel(b.s2, a.s2, ss));
+            }
             dev[i] = d;
         }
         wr(lower); wr(upper); wr(avg); wr(dev);
