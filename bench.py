@@ -134,14 +134,29 @@ def time_problem(text, steps, warmup):
     return t1 - t0, kt.value / nk, tt.value / nk
 
 
+def stream_ceiling(planes_in, planes_out, cells):
+    """GB/s this device streams for the step's byte count with no stencil at all (gpf_stream_probe): the data-sheet 8 TB/s
+    is not attainable, and boxes of one pool differ by ~20 % in what they do attain."""
+    import ctypes as C
+    from gapflow_amd import _lib
+    ms = C.c_double(0)
+    _lib.check(_lib.require_device().gpf_stream_probe(0, planes_in, planes_out, cells, 20, C.byref(ms)))
+    return (planes_in + planes_out) * 8.0 * cells / (ms.value / 1e3) / 1e9
+
+
 def roofline(kernel_ms, cells, bytes_per_cell, traffic_kind, kernel):
     """HBM roofline of the step kernel: bytes COMPULSORY for this workload per launch / mean launch duration."""
     alg = bytes_per_cell * cells
     achieved = alg / (kernel_ms / 1e3) / 1e9
     traffic, src = measured_traffic(traffic_kind)
+    planes_in = 6 if traffic_kind == 'planes' else 3
+    stream = stream_ceiling(planes_in, 3, cells)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": src, "kernel": kernel, "kernel_ms": kernel_ms,
-            "algorithmic_bytes_per_cell": bytes_per_cell, "algorithmic_bytes_per_launch": alg}
+            "algorithmic_bytes_per_cell": bytes_per_cell, "algorithmic_bytes_per_launch": alg,
+            "stream_ceiling_GBps": stream, "frac_of_stream_ceiling": achieved / stream,
+            "stream_ceiling_note": f"elementwise {planes_in}-in / 3-out fp64 kernel of the same byte count on this device, "
+                                   "timed in this run (gpf_stream_probe)"}
 
 
 def run_single(args):

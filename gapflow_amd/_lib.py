@@ -88,6 +88,7 @@ SIGNATURES = {
     'gpf_p2p_connect': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     'gpf_p2p_set_timeout': (C.c_int, [C.c_void_p, C.c_double]),
     'gpf_upload_beyond': (C.c_int, [C.c_void_p, C.c_int, _DP, C.c_size_t]),
+    'gpf_stream_probe': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _DP]),
     'gpf_step_p2p': (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
     'gpf_stage_message': (C.c_int, [C.c_void_p]),
     'gpf_stage_absorb': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),

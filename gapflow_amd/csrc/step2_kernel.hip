@@ -243,22 +243,29 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
     const double* const lane_t = reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.topo) + lane_bytes);
     const double* const lane_ls = HAS_LS ? reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.Ls) + lane_bytes) : nullptr;
     auto issue = [&](int n, Raw& r) {
-        const int ix = D > 0 ? n : L.Nx + 1 - n;
+        // Beyond the chunk's last row nothing is needed, but the number of loads in flight behind a row must not change
+        // (the waits count them): the request then goes, for every plane, to the density row just requested -- one
+        // cached kilobyte instead of a row of every plane.
+        const bool dummy = n > n_last + 1;
+        const int ix = D > 0 ? min(n, n_last + 1) : L.Nx + 1 - min(n, n_last + 1);
         const long long rb = (long long)ix * L.pitch;       // wave-uniform
-        asm_load16(r.q[0], lane_q + rb); asm_load16(r.q[1], lane_q + L.plane + rb); asm_load16(r.q[2], lane_q + 2 * L.plane + rb);
+        const long long p1 = dummy ? 0 : L.plane, p2 = dummy ? 0 : 2 * L.plane;
+        asm_load16(r.q[0], lane_q + rb); asm_load16(r.q[1], lane_q + p1 + rb); asm_load16(r.q[2], lane_q + p2 + rb);
         if (TOPO == 0) {
-            asm_load16(r.t[0], lane_t + rb); asm_load16(r.t[1], lane_t + L.plane + rb); asm_load16(r.t[2], lane_t + 2 * L.plane + rb);
+            const double* t0 = dummy ? lane_q : lane_t;
+            asm_load16(r.t[0], t0 + rb); asm_load16(r.t[1], t0 + p1 + rb); asm_load16(r.t[2], t0 + p2 + rb);
         } else if (TOPO == 1 || TOPO == 3) {
             r.th = uniform_load(a.topo_line + ix); r.thx = uniform_load(a.topo_line + (L.Nx + 2) + ix);
             r.thy = TOPO == 1 ? uniform_load(a.topo_line + 2 * (L.Nx + 2) + ix) : 0.0;
         }
-        if (HAS_LS) asm_load16(r.ls[0], lane_ls + rb);
+        if (HAS_LS) asm_load16(r.ls[0], (dummy ? lane_q : lane_ls) + rb);
     };
-    // wait until row r has landed: exactly GPF_K2_AHEAD row requests (NL loads each) have been issued after it
+    // wait until row r has landed: exactly AHEAD row requests (NL loads each) have been issued after it
+    constexpr int AHEAD_ROWS = PIEZO ? 1 : GPF_K2_AHEAD;
     auto arrive = [&](Raw& r) {
-        asm_wait3<GPF_K2_AHEAD * NL>(r.q[0], r.q[1], r.q[2]);
-        if (TOPO == 0) asm_wait3<GPF_K2_AHEAD * NL>(r.t[0], r.t[1], r.t[2]);
-        if (HAS_LS) asm_wait1<GPF_K2_AHEAD * NL>(r.ls[0]);
+        asm_wait3<AHEAD_ROWS * NL>(r.q[0], r.q[1], r.q[2]);
+        if (TOPO == 0) asm_wait3<AHEAD_ROWS * NL>(r.t[0], r.t[1], r.t[2]);
+        if (HAS_LS) asm_wait1<AHEAD_ROWS * NL>(r.ls[0]);
     };
     auto unpack = [&](const Raw& r, Row2& o) {
         o.rho[0] = D > 0 ? r.q[0].x : r.q[0].y; o.rho[1] = D > 0 ? r.q[0].y : r.q[0].x;
@@ -341,7 +348,8 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
     // out, then the wave waits for row n alone (requested AHEAD rows ago; a row of arithmetic lasts longer than an
     // HBM round trip).  AHEAD + 1 row buffers rotate by NAME: the loop body is a lambda instantiated once per
     // buffer, so no register copies are needed to advance the window.
-    constexpr int AHEAD = GPF_K2_AHEAD;
+    // (the piezo-viscosity closures -- exp / pow per cell -- leave no registers for the third buffer: one row ahead there)
+    constexpr int AHEAD = PIEZO ? 1 : GPF_K2_AHEAD;
     Raw rowbuf[AHEAD + 1];
     issue(n_first - 1, rowbuf[0]);
     if (AHEAD == 2) issue(n_first, rowbuf[1]);
@@ -352,9 +360,9 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
 
     // one row of the march: `raw` holds (or is about to hold) row n, `spare` is the buffer row n-1 has vacated
     auto march = [&](const int n, Raw& raw, Raw& spare) {
-        // Beyond the chunk's last row the request repeats that row (an L2 hit, never used): the number of loads in
-        // flight behind `raw` is then the same in every iteration, and the wait needs no case distinction.
-        issue(min(n + AHEAD, n_last + 1), spare);
+        // (beyond the chunk's last row `issue` sends a dummy request: the number of loads in flight behind `raw` is the
+        // same in every iteration, and the wait needs no case distinction)
+        issue(n + AHEAD, spare);
         arrive(raw);
         Row2 cur;
         unpack(raw, cur);

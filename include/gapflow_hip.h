@@ -278,6 +278,11 @@ int gpf_gp_clear_model(gpf_handle* h, int which);
  * gp.py:408).  on_open_step != 0: evaluate on the working field of an open step. */
 int gpf_gp_variance(gpf_handle* h, int which, int on_open_step, double* max_var);
 
+/* Diagnostic: time of one pass of an elementwise kernel that reads `nin` and writes `nout` fp64 planes of
+ * `doubles_per_plane` elements (16 bytes per lane, grid-stride): what THIS device streams for the byte count of a fused
+ * step.  bench.py reports it beside the step kernel's HBM figure (no reference counterpart: the reference has no device). */
+int gpf_stream_probe(int device, int nin, int nout, int64_t doubles_per_plane, int reps, double* ms_per_pass);
+
 #ifdef __cplusplus
 }
 #endif

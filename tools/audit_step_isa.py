@@ -1,0 +1,114 @@
+"""ISA audit of k_step2's hand-pipelined row loads (csrc/step2_kernel.hip), on the CPU (hipcc cross-compiles):
+
+    python tools/audit_step_isa.py
+
+The row loads are inline-asm `global_load_dwordx4`; hipcc treats their destination registers as written when the asm
+statement ends, so it could legally copy, spill or reuse them before the data has landed (CDNA4 guide 5.7, item 1).  For
+a few instantiations of the kernel this script compiles the kernel to assembly and checks that
+  * between each row load and the hand-written `s_waitcnt vmcnt(N)` that guards its row (two loop bodies later, and from
+    the prologue's loads up to the loop) no compiler instruction mentions a destination register,
+  * and reports scratch accesses / compiler-visible vector loads inside the march loop (hipcc's `vmcnt` waits for them
+    drain the pipeline: a speed matter, not a correctness one; the piezo-viscosity variants spill).
+Exit status 0 = no register hazard."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, 'gapflow_amd', 'csrc')
+VARIANTS = ['0, false, false, 1, 0', '0, false, false, -1, 0', '0, false, false, 1, 1', '0, false, false, 1, 2',
+            '0, false, false, 1, 3', '0, true, false, 1, 0', '0, false, true, 1, 0', '5, true, true, -1, 0']
+
+
+def regs_of(tok):
+    out = set()
+    for m in re.finditer(r'v\[(\d+):(\d+)\]', tok):
+        out |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r'\bv(\d+)\b', tok):
+        out.add(int(m.group(1)))
+    return out
+
+
+def audit(lines):
+    start = next(i for i, l in enumerate(lines) if 'Inner Loop Header' in l)
+    name = re.match(r'^(\.LBB\d+_\d+):', lines[start]).group(1)[2:]
+    end = max(i for i, l in enumerate(lines) if re.search(r'in Loop: Header=' + name + r'\b', l))
+    while not lines[end + 1].startswith('.LBB') and 'Lfunc_end' not in lines[end + 1]:
+        end += 1
+    problems, slow = [], []
+    # prologue: loads issued before the loop stay in flight until the loop consumes them
+    inflight, in_asm = set(), False
+    for i, l in enumerate(lines[:start]):
+        t = l.strip()
+        if t.startswith(';;#ASMSTART'):
+            in_asm = True
+        elif t.startswith(';;#ASMEND'):
+            in_asm = False
+        elif in_asm and t.startswith('global_load_dwordx4'):
+            inflight |= regs_of(t.split(',')[0])
+        elif not in_asm and t and t[0] not in ';.' and inflight and regs_of(t) & inflight:
+            problems.append(f'prologue line {i}: {t}')
+    body = lines[start:end + 1]
+    events, in_asm = [], False
+    for i, l in enumerate(body):
+        t = l.strip()
+        if t.startswith(';;#ASMSTART'):
+            in_asm = True
+        elif t.startswith(';;#ASMEND'):
+            in_asm = False
+        elif in_asm and t.startswith('global_load_dwordx4'):
+            events.append((i, 'load', regs_of(t.split(',')[0])))
+        elif in_asm and t.startswith('s_waitcnt'):
+            events.append((i, 'wait', set()))
+        elif not in_asm and t and t[0] not in ';.':
+            events.append((i, 'ins', regs_of(t)))
+            if t.startswith('scratch_') or t.startswith('global_load') or t.startswith('buffer_load'):
+                slow.append(f'loop line {i}: compiler-visible memory access {t}')
+    groups, cur = [], None
+    for idx, kind, regs in events:
+        if kind == 'load':
+            cur = cur or []
+            cur.append((idx, regs))
+        elif kind == 'wait' and cur:
+            groups.append(cur)
+            cur = None
+    waits = [next(idx for idx, kind, _ in events if kind == 'wait' and idx > g[0][0]) for g in groups]
+    n = len(groups)
+    for k, loads in enumerate(groups):
+        target = waits[(k + 2) % n] if n == 3 else waits[(k + 1) % n]
+        for gidx, regs in loads:
+            span = [(i, r) for i, kind, r in events if kind == 'ins' and (gidx < i < target if target > gidx else (i > gidx or i < target))]
+            for i, r in span:
+                if r & regs:
+                    problems.append(f'loop line {i}: touches in-flight v{sorted(r & regs)}: {body[i].strip()}')
+    return n, problems, slow
+
+
+def main():
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, 't.hip')
+        with open(src, 'w') as f:
+            f.write('#include <hip/hip_runtime.h>\n#include "step_kernel.hip"\n#include "aux_kernels.hip"\n#include "step2_kernel.hip"\nusing namespace gpf;\n')
+            for v in VARIANTS:
+                f.write(f'template __global__ void gpf::k_step2<{v}>(const Step2Args, const Phys);\n')
+        asm = os.path.join(tmp, 't.s')
+        subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=fast', '-I', CSRC, '-S',
+                        '--cuda-device-only', src, '-o', asm], check=True, capture_output=True)
+        text = open(asm).read().split('\n')
+    bad = 0
+    starts = [i for i, l in enumerate(text) if re.match(r'^_ZN3gpf7k_step2I.*:', l)]
+    for a in starts:
+        b = next(i for i in range(a, len(text)) if text[i].startswith('.Lfunc_end'))
+        n, problems, slow = audit(text[a:b])
+        print(text[a].split(':')[0], f'{n} row-load groups in the march,', 'registers safe' if not problems else f'{len(problems)} REGISTER HAZARDS',
+              '' if not slow else f'; {len(slow)} compiler-visible memory accesses in the loop (spills: slow, not wrong)')
+        for p in problems[:10]:
+            print('   ', p)
+        bad += len(problems)
+    return 1 if bad else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -64,7 +64,7 @@ def main():
     for (name, ctr), v in sums.items():
         means.setdefault(name, {})[ctr] = v / max(1, len(counts[(name, ctr)]))
     json.dump(means, open(os.path.join(out, 'pmc_means_per_launch.json'), 'w'), indent=1, sort_keys=True)
-    for kind, marker in (('line', ', 1>'), ('planes', ', 0>')):
+    for kind, marker in (('line', ', 3>'), ('planes', ', 0>')):      # TOPO template argument of k_step2: x-only gap / planes
         step = [k for k in means if 'k_step2' in k and k.rstrip().endswith(marker)]
         if step and 'FETCH_SIZE' in means[step[0]] and 'WRITE_SIZE' in means[step[0]]:
             m = means[step[0]]
