@@ -71,6 +71,7 @@ struct gpf_handle {
     Partial* partials = nullptr;
     unsigned int* arrive = nullptr;         // [0] blocks done: k_step2 (fused) / k_ghost_fill (finish_step); [1], [2]: k_begin_slab's arrivals and time-outs
     long long p2p_timeout_ticks = P2P_TIMEOUT_TICKS;
+    bool split_edges = false;               // GPF_STEP_UNFUSED_EDGES at gpf_create: edge work in separate launches
     bool g1_ready = false;                  // g1 already holds the next step's stage-1 ghost values (k_begin_slab wrote them)
     Partial* block_partials = nullptr;      // one record per edge-kernel block
     int nghost_blocks = 0;
@@ -202,6 +203,7 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
         h->E.value[e] = cfg->bc_value[e];
     }
     h->E.halo[0] = cfg->halo_lo; h->E.halo[1] = cfg->halo_hi;
+    h->split_edges = std::getenv("GPF_STEP_UNFUSED_EDGES") != nullptr;
     make_phys(*cfg, h->P);
 
     const size_t plane_b = (size_t)L.plane * sizeof(double);
@@ -609,11 +611,9 @@ static Strip2Geom strip2_geom(const Layout& L, int D) {
     return G;
 }
 
-// ghost cells, stage-1 ghost data and the commit inside k_step2: every handle that is not a slab
-static bool step2_fused(const gpf_handle* h) {
-    static const bool off = std::getenv("GPF_STEP_UNFUSED_EDGES") != nullptr;
-    return !off && h->E.halo[0] == 0 && h->E.halo[1] == 0;
-}
+// Edge work inside k_step2 (ghost cells, stage-1 ghost data, slab message, reductions; the commit too unless the handle is a
+// slab).  GPF_STEP_UNFUSED_EDGES=1 at gpf_create selects the older split form instead, kept as a cross-check.
+static bool step2_fused(const gpf_handle* h) { return !h->split_edges; }
 
 // One wave marches over one row chunk of one 126-column strip; the chunks are sized so that all waves are resident at
 // once (a single round, no tail) when the problem is big enough.
@@ -654,6 +654,8 @@ static int plan_step2(gpf_handle* h) {
     return GPF_OK;
 }
 
+constexpr int SLAB_COMMIT_BLOCKS = 24;     // k_begin_slab without stage-1 work: a 6-row copy and the commit
+
 static P2PArgs p2p_args(gpf_handle* h, bool on) {
     P2PArgs c;
     c.on = on ? 1 : 0; c.nranks = h->p2p.nranks; c.rank = h->p2p.rank; c.rank_lo = h->p2p.rank_lo; c.rank_hi = h->p2p.rank_hi;
@@ -684,7 +686,7 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     const int mc = h->cfg.mc_order;
     const int D = mc == 0 ? ((h->next_step % 2 == 0) ? 1 : -1) : (((mc + 1) / 2) ? 1 : -1);
     h->next_step += 1;
-    const bool fused = step2_fused(h) && slab_out == nullptr && !p2p;
+    const bool fused = step2_fused(h);
     const Strip2Geom& G2 = h->geom2[D > 0 ? 0 : 1];
     const int np_step = G2.nstrips * h->nchunks2;
     Step2Args a2;
@@ -696,6 +698,8 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     GhostArgs g;
     GPF_TRY(ghost_args(h, honor_stop, g));
     const bool slab = slab_out != nullptr;
+    a2.seam[0] = g.seam[0]; a2.seam[1] = g.seam[1];
+    a2.out = slab_out; a2.msg = (slab && !p2p) ? h->halo : nullptr; a2.p2p = p2p_args(h, p2p);
     FinishArgs f;
     f.partials = h->partials; f.st = h->st;
     f.log = h->log; f.log_base = log_base; f.log_cap = h->log_cap; f.out = slab_out; f.honor_stop = honor_stop;
@@ -707,21 +711,23 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     gf.qa = h->q[0]; gf.qb = h->q[1]; gf.st = h->st;
     gf.L = L; gf.E = h->E; gf.honor_stop = honor_stop;
 
-    // Launches per step.  A handle that is not a slab: k_step2 alone (ghost cells, stage-1 ghost data, reductions and the
-    // commit happen inside it).  A slab:
+    // Launches per step: k_step2 alone (ghost cells, stage-1 ghost data, reductions and -- unless the handle is a slab --
+    // the commit happen inside it).  A slab's k_step2 leaves its boundary rows and its record in the message / the peers'
+    // mailboxes; after the exchange k_begin_slab scatters the neighbours' rows, reduces the records in rank order and
+    // commits (launched here for the peer-to-peer transport, by gpf_step_commit for the all-gather).
+    // The split form (GPF_STEP_UNFUSED_EDGES=1):
     //   k_ghost_stage1  stage-1 values on the downwind ghost row / column (needs the dt the previous step committed)
     //   k_step2         the fused predictor + corrector + average over the interior
     //   k_ghost_fill    ghost cells of the new field + the slab's boundary rows into its message / its peers' mailboxes;
-    //                   its last block to finish reduces all records into this rank's record
-    //   k_begin_slab    (after the exchange) scatter the neighbours' rows, rank-ordered reduction, commit, and
-    //                   k_ghost_stage1's job for the next step
+    //                   its last block to finish reduces all records into this rank's record or commits
+    //   k_begin_slab    (slabs, after the exchange) as above, plus k_ghost_stage1's job for the next step
     const int ntiles = (L.Nx + L.Ny + 63) / 64;                 // stage-1 ghost work: 64 items per block
     const dim3 ggrid(std::min(ntiles, 512));
     const int nsend = slab ? std::min((6 * L.pitch + 1023) / 1024, 256) : 0;        // block_partials holds 1024
     WaitArgs w;
     w.qa = h->q[0]; w.qb = h->q[1]; w.st = h->st; w.log = h->log; w.log_base = log_base; w.log_cap = h->log_cap;
     w.L = L; w.E = h->E; w.honor_stop = honor_stop; w.arrive = h->arrive + 1; w.timeout_ticks = h->p2p_timeout_ticks; w.p2p = f.p2p;
-    w.gathered = nullptr; w.msg_len = 0; w.nranks = 0; w.rank_lo = w.rank_hi = -1;
+    w.gathered = nullptr; w.msg_len = 0; w.nranks = 0; w.rank_lo = w.rank_hi = -1; w.stage1 = fused ? 0 : 1;
     const bool has_ls = h->Ls != nullptr;
     if (fused) {
         // the whole step in one launch (step2_kernel.hip)
@@ -729,6 +735,12 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
         if (ev0) hipEventRecord(ev0, h->stream);
         hipLaunchKernelGGL(k2, dim3(h->nblocks2), dim3(256), 0, h->stream, a2, h->P);
         if (ev1) hipEventRecord(ev1, h->stream);
+        if (p2p) {                          // wait for the peers, scatter their rows, commit
+            const dim3 cgrid(SLAB_COMMIT_BLOCKS);
+            EOS_DISPATCH(h->cfg.eos, {
+                hipLaunchKernelGGL((k_begin_slab<EOS_, false, false, false, true>), cgrid, dim3(256), 0, h->stream, g, w, h->P);
+            });
+        }
         h->g1_ready = false;
         HIP_TRY(hipGetLastError());
         return GPF_OK;

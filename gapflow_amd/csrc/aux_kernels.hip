@@ -278,31 +278,33 @@ __device__ __forceinline__ void merge_published(Acc& acc, const Partial* slot) {
 }
 
 // the last block: combine the blocks' records and commit, or -- slab -- publish this rank's record
-__device__ inline void finish_tail(const FinishArgs& a, Acc* sm) {
+// (pieces instead of a FinishArgs: k_step2 passes references into its own kernel arguments -- a by-value copy of the
+// mailbox table, indexed by thread, would live in scratch memory)
+__device__ inline void finish_tail(StepState* st, LogEntry* log, long long log_base, long long log_cap, double* out,
+                                   const Partial* block_partials, const P2PArgs& p2p, Acc* sm) {
     __shared__ double rec_sm[8];
-    StepState* st = a.st;
     Acc acc; acc.zero();
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) merge_published(acc, a.block_partials + i);
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) merge_published(acc, block_partials + i);
     acc = block_reduce(acc, sm);
     if (threadIdx.x == 0) {
-        if (a.out) {
+        if (out) {
             // slab mode: NaN maxima travel as +inf so that any reduction order keeps them
             const double inf = __builtin_inf();
-            a.out[0] = acc.ekin;
-            a.out[1] = acc.v2 != acc.v2 ? inf : acc.v2;
-            a.out[2] = acc.c2 != acc.c2 ? inf : acc.c2;
-            a.out[3] = (double)acc.flags;
-            a.out[4] = a.out[5] = a.out[6] = a.out[7] = 0.0;
-            for (int k = 0; k < 8; ++k) rec_sm[k] = a.out[k];
+            out[0] = acc.ekin;
+            out[1] = acc.v2 != acc.v2 ? inf : acc.v2;
+            out[2] = acc.c2 != acc.c2 ? inf : acc.c2;
+            out[3] = (double)acc.flags;
+            out[4] = out[5] = out[6] = out[7] = 0.0;
+            for (int k = 0; k < 8; ++k) rec_sm[k] = out[k];
         } else {
-            commit_step(st, acc.ekin, acc.v2, acc.c2, acc.flags, a.log, a.log_base, a.log_cap);
+            commit_step(st, acc.ekin, acc.v2, acc.c2, acc.flags, log, log_base, log_cap);
         }
     }
-    if (a.p2p.on) {
+    if (p2p.on) {
         // message n = seq + 1: the rows are in the neighbours' mailboxes (send_rows_block: write-through stores,
         // drained before the blocks arrived); now the record to everybody, then the flags
         __syncthreads();
-        const P2PArgs& c = a.p2p;
+        const P2PArgs& c = p2p;
         const unsigned long long n = *c.seq + 1;
         const int slot = (int)(n & 1);
         if (threadIdx.x < c.nranks) {
@@ -312,6 +314,10 @@ __device__ inline void finish_tail(const FinishArgs& a, Acc* sm) {
             __hip_atomic_store(&hd->flag[slot][c.rank], n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+
+__device__ inline void finish_tail(const FinishArgs& a, Acc* sm) {
+    finish_tail(a.st, a.log, a.log_base, a.log_cap, a.out, a.block_partials, a.p2p, sm);
 }
 
 // Called by every block of the edge kernel when its own work is done, with the reductions over the cells it wrote
@@ -512,6 +518,7 @@ struct WaitArgs {
     const double* gathered;     // all-gather source: nranks messages [first row | last row | record] of msg_len doubles
     long long msg_len;
     int nranks, rank_lo, rank_hi;
+    int stage1;                 // also prepare the next step's stage-1 ghost data (the split step, GPF_STEP_UNFUSED_EDGES)
 };
 // MAILBOX: rows and records are waited for in this rank's mailbox (peer-to-peer transport); otherwise they are read from
 // the buffer an all-gather has filled before this launch (same layout as gpf_slab_message, rank order).
@@ -574,7 +581,9 @@ __global__ __launch_bounds__(256) void k_begin_slab(const GhostArgs g, const Wai
             const double* src = side ? row_hi : row_lo;
             if (src) q[k * L.plane + (long long)(side ? L.Nx + 1 : 0) * L.pitch + i] = src[k * L.pitch + i];
         }
-        // stage-1 ghost values of step+1 with the dt the commit is about to fix
+        // the split step: stage-1 ghost values of step+1 with the dt the commit is about to fix (the fused step kernel forms
+        // them itself)
+        if (a.stage1) {
         const double c2_eff = (flags & 4) ? __builtin_nan("") : c2;
         const double dt = st->adaptive ? st->CFL * critical_dt(st, v2, c2_eff) : st->dt;
         const int D = direction_of_step(st, st->step + 1);
@@ -582,6 +591,7 @@ __global__ __launch_bounds__(256) void k_begin_slab(const GhostArgs g, const Wai
         fld.q = q; fld.L = L; fld.row_lo = row_lo; fld.row_hi = row_hi;
         const int ntiles = (L.Ny + L.Nx + 63) / 64;
         for (int tile = block; tile < ntiles; tile += nblocks) ghost_stage1_tile<EOS, HAS_LS, PIEZO, XONLY>(fld, g, P, D, tile * 64, dt, tiles);
+        }
     }
     // the last block to get here writes the committed state (the others have read everything they need from it)
     __syncthreads();

@@ -16,8 +16,13 @@
 //     row chunk / the last strip form the stage-1 field on the downwind ghost row / column themselves
 //     (problem.py:560), and the last workgroup to finish reduces the per-block records and commits dt,
 //     residual and step count on the device (problem.py:571-586).
-//   * slabs (halo rows filled by a neighbour exchange) run the same kernel with `fused = 0`: ghost data comes
-//     from g1x / g1y and the edge kernels of step_kernel.hip / aux_kernels.hip follow as before.
+//   * slabs (outer rows filled by a neighbour exchange) run the same launch: the waves that finish a slab's first /
+//     last row also copy it -- ghost columns included -- into the all-gather message or straight into the
+//     neighbour's mailbox, the stage-1 field across a periodic seam is formed from the halo row and the seam's
+//     topography, and the last workgroup leaves the rank's RECORD (and, peer-to-peer, the sequence flags) instead of
+//     committing; k_begin_slab (aux_kernels.hip) scatters the neighbours' rows and commits after the exchange.
+//   * `fused = 0` (GPF_STEP_UNFUSED_EDGES=1) is the older split form, kept as a cross-check: ghost data from
+//     g1x / g1y, edge kernels of step_kernel.hip / aux_kernels.hip before and after.
 //
 // Logical indices as in step_kernel.hip: n (rows) and m (columns) increase DOWNWIND of the predictor,
 //   ix = n for D = +1, Nx+1-n for D = -1, likewise iy from m.
@@ -56,7 +61,11 @@ struct Strip2Geom {
 struct Step2Args {
     const double* qa; const double* qb;
     const double* topo; const double* topo_line; const double* Ls;
-    const double* g1x; const double* g1y;   // slabs: stage-1 ghost data prepared by k_ghost_stage1 / k_begin_slab
+    const double* g1x; const double* g1y;   // fused = 0: stage-1 ghost data prepared by k_ghost_stage1 / k_begin_slab
+    const double* seam[2];                  // topography rows across a periodic slab seam (gpf_set_seam_topo), per x edge
+    double* out;                            // slab: the rank's 8-double record goes here and nothing is committed
+    double* msg;                            // slab, all-gather transport: [first row | last row] of the local message
+    P2PArgs p2p;                            // slab, peer-to-peer transport: the neighbours' mailboxes
     StepState* st;
     Partial* partials;                      // fused = 0: one record per wave (chunk-major), folded by k_ghost_fill
     Partial* block_partials;                // fused = 1: one record per block, folded by the last block
@@ -312,8 +321,26 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
     //      row 1, from the stored rows 0 and 1 (problem.py:560, 682-695) ----
     if (fused && dw_row_is_ghost && x_periodic) {
         Row2 r0, r1;
-        load(0, r0);
-        load(1, r1);
+        if (a.E.halo[e_dw_x] == 2) {
+            // periodic seam between slabs: the partner row's state sits in this slab's outer row (logical row Nx+1), its
+            // upwind neighbour is this slab's last row; their topography belongs to the far slab's rows 1 and 0
+            load(L.Nx, r0);
+            load(L.Nx + 1, r1);
+            auto seam_topo = [&](const double* __restrict__ t, Row2& r) {
+                if (TOPO == 1 || TOPO == 3) {
+                    r.h[0] = r.h[1] = t[L.off + 1]; r.hx[0] = r.hx[1] = t[L.pitch + L.off + 1];
+                    r.hy[0] = r.hy[1] = TOPO == 1 ? t[2 * L.pitch + L.off + 1] : 0.0;
+                } else {
+                    pair(t, r.h[0], r.h[1]); pair(t + L.pitch, r.hx[0], r.hx[1]); pair(t + 2 * L.pitch, r.hy[0], r.hy[1]);
+                }
+                if (HAS_LS) pair(t + 3 * L.pitch, r.Ls[0], r.Ls[1]);
+            };
+            seam_topo(a.seam[e_dw_x] + 4 * L.pitch, r0);
+            seam_topo(a.seam[e_dw_x], r1);
+        } else {
+            load(0, r0);
+            load(1, r1);
+        }
         double fy[2][3], q1[2][3];
         CellFlux f0[2], f1[2];
         const RowCoef rc0 = TOPO == 3 ? row_coefficients(r0.h[0], r0.hx[0], P) : RowCoef();
@@ -505,10 +532,30 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
             const long long o = (long long)ix * L.pitch + L.off + iy;
             v[0] = qo0[o]; v[1] = qo1[o]; v[2] = qo2[o];
         };
-        auto put = [&](int ix, int iy, const double v[3]) {
+        auto put = [&](int ix, int iy, const double v[3], double w) {
             const long long o = (long long)ix * L.pitch + L.off + iy;
             qo0[o] = v[0]; qo1[o] = v[1]; qo2[o] = v[2];
-            red.cell(v[0], v[1], v[2], 1.0, P);
+            red.cell(v[0], v[1], v[2], w, P);
+        };
+        // slabs: where this slab's first (e = 0) / last (e = 1) row travels -- the local all-gather message, or the
+        // neighbour's mailbox (its slot of message seq + 1: row `1 - e` there, i.e. its outer row on my side)
+        double* send_to[2] = {nullptr, nullptr};
+        if (a.p2p.on) {
+            const int slot = (int)((*a.p2p.seq + 1) & 1);
+            if (a.E.halo[0] && a.p2p.rank_lo >= 0) send_to[0] = p2p_rows(a.p2p.box[a.p2p.rank_lo], slot, 1, L.pitch);
+            if (a.E.halo[1] && a.p2p.rank_hi >= 0) send_to[1] = p2p_rows(a.p2p.box[a.p2p.rank_hi], slot, 0, L.pitch);
+        } else if (a.msg) {
+            if (a.E.halo[0]) send_to[0] = a.msg;
+            if (a.E.halo[1]) send_to[1] = a.msg + 3 * L.pitch;
+        }
+        auto send = [&](int e, int iy, const double v[3]) {
+            double* d = send_to[e] + L.off + iy;
+            for (int c = 0; c < 3; ++c) {
+                if (a.p2p.on)       // a peer's memory: write-through at system scope, drained before this block arrives
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(d + c * L.pitch), (unsigned long long)__double_as_longlong(v[c]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                else d[c * L.pitch] = v[c];
+            }
         };
         // ghost columns: one lane per row of the chunk
         const int m_out_lo = max(G.w0 + strip * STRIP2 + 1, 1), m_out_hi = min(G.w0 + strip * STRIP2 + STRIP2, L.Ny);
@@ -519,11 +566,15 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
                 double v[3], g[3];
                 get(ix, src_col[ey], v);
                 for (int c = 0; c < 3; ++c) g[c] = ghost_rule(a.E, 2 + ey, c, v[c]);
-                put(ix, ey ? L.Ny + 1 : 0, g);
+                // a row next to a periodic slab seam also stands in for the far slab's ghost row
+                put(ix, ey ? L.Ny + 1 : 0, g, 1.0 + (ix == seam_row_lo ? 1.0 : 0.0) + (ix == seam_row_hi ? 1.0 : 0.0));
+                if (ix == 1 && send_to[0]) send(0, ey ? L.Ny + 1 : 0, g);
+                if (ix == L.Nx && send_to[1]) send(1, ey ? L.Ny + 1 : 0, g);
             }
         }
         // ghost rows (and corners): the lanes re-read the source row at their own output columns
         for (int e = 0; e < 2; ++e) {
+            if (a.E.halo[e]) continue;                                              // a neighbour's row: the exchange fills it
             if (src_row[e] < ix_lo || src_row[e] > ix_hi) continue;                 // wave-uniform: not this chunk's row
             const int ixg = e ? L.Nx + 1 : 0;
             for (int k = 0; k < 2; ++k) {
@@ -532,14 +583,26 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
                 double v[3], g[3], gc[3];
                 get(src_row[e], iy, v);
                 for (int c = 0; c < 3; ++c) g[c] = ghost_rule(a.E, e, c, v[c]);
-                put(ixg, iy, g);
+                put(ixg, iy, g, 1.0);
                 for (int ey = 0; ey < 2; ++ey) {
                     if (iy != src_col[ey]) continue;
                     for (int c = 0; c < 3; ++c) gc[c] = ghost_rule(a.E, 2 + ey, c, g[c]);
-                    put(ixg, ey ? L.Ny + 1 : 0, gc);
+                    put(ixg, ey ? L.Ny + 1 : 0, gc, 1.0);
                 }
             }
         }
+        // slabs: the first / last row, at the lanes' own output columns
+        for (int e = 0; e < 2; ++e) {
+            const int ixb = e ? L.Nx : 1;
+            if (!send_to[e] || ixb < ix_lo || ixb > ix_hi) continue;                // wave-uniform
+            for (int k = 0; k < 2; ++k) {
+                if (!(k ? out1 : out0)) continue;
+                double v[3];
+                get(ixb, k ? iy1 : iy0, v);
+                send(e, k ? iy1 : iy0, v);
+            }
+        }
+        if (a.p2p.on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
     // ---- wave reduction: the record is valid in lane 0 ----
@@ -595,6 +658,7 @@ __global__ __launch_bounds__(256, ((TOPO == 1 || TOPO == 3) ? GPF_K2_MINWAVES_LI
         return;
     }
     // ---- fused: one record per block; the last block to arrive folds them and commits the step ----
+    // (the barrier below also puts every wave's drained stores -- message rows included -- before the arrival)
     if (lane == 0) red_sm[wv] = own;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -607,11 +671,8 @@ __global__ __launch_bounds__(256, ((TOPO == 1 || TOPO == 3) ? GPF_K2_MINWAVES_LI
     }
     __syncthreads();
     if (!s_last) return;
-    Acc acc;
-    acc.zero();
-    for (int i = threadIdx.x; i < nb; i += blockDim.x) merge_published(acc, a.block_partials + i);
-    acc = block_reduce(acc, red_sm);
-    if (threadIdx.x == 0) commit_step(a.st, acc.ekin, acc.v2, acc.c2, acc.flags, a.log, a.log_base, a.log_cap);
+    // (a slab leaves its record in the message / the peers' mailboxes instead: the commit follows the exchange)
+    finish_tail(a.st, a.log, a.log_base, a.log_cap, a.out, a.block_partials, a.p2p, red_sm);
 }
 
 }  // namespace gpf

@@ -318,6 +318,42 @@ def test_n_slabs_are_bitwise_the_one_slab_run(hiplib, tmp_path, p2p):
         assert all(d == dt1[0] for d in dtn)
 
 
+WIDE = SIM.replace('Nx: 150, Ny: 70', 'Nx: 90, Ny: 300')         # three strips of the step kernel, x-only gap
+ASPERITY = """
+options: {silent: True}
+grid: {Nx: 60, Ny: 270, Lx: 6.e-4, Ly: 2.7e-3}
+geometry: {type: asperity, hmin: 2.e-6, hmax: 1.e-5, num: 1, U: 10., V: 5.}
+numerics: {CFL: 0.4, adaptive: 1, MC_order: 0, tol: 1.e-12, max_it: 1000}
+properties: {EOS: DH, shear: 0.0794, bulk: 0., rho0: 877.7007}
+"""
+
+
+@pytest.mark.parametrize('p2p', [False, True], ids=['allgather', 'p2p'])
+@pytest.mark.parametrize('text', [SIM, DIRICHLET, WIDE, ASPERITY], ids=['periodic', 'dirichlet', 'wide', 'asperity-planes'])
+def test_fused_slab_step_is_bitwise_the_split_step(hiplib, tmp_path, monkeypatch, text, p2p):
+    """The slab step with its edge work inside k_step2 (message rows, stage-1 field across the seam, record; one launch
+    plus the commit) against the older split form (GPF_STEP_UNFUSED_EDGES=1: k_ghost_stage1 / k_ghost_fill around the
+    stencil): same field bit for bit -- outer rows included -- and the same dt on 3 slabs; the kinetic energy is summed in
+    a different order."""
+    import torch.multiprocessing as mp
+    nsteps, world = 21, 3
+    runs = {}
+    for mode in ('fused', 'split'):
+        if mode == 'split':
+            monkeypatch.setenv('GPF_STEP_UNFUSED_EDGES', '1')
+        else:
+            monkeypatch.delenv('GPF_STEP_UNFUSED_EDGES', raising=False)
+        out = tmp_path / mode
+        out.mkdir()
+        mp.spawn(_slab_worker, args=(world, _free_port(), text, nsteps, str(out), p2p), nprocs=world, join=True)
+        runs[mode] = [np.load(out / f'rank{r}.npz') for r in range(world)]
+    for a, b in zip(runs['fused'], runs['split']):
+        assert int(a['step']) == nsteps == int(b['step']) and int(a['invalid']) == 0
+        assert np.array_equal(a['q'], b['q']), f"{np.abs(a['q'] - b['q']).max():.3e}"
+        assert float(a['dt']) == float(b['dt'])
+        np.testing.assert_allclose(a['ekin'], b['ekin'], rtol=1e-13)
+
+
 def _timeout_worker(rank, world, port, text, out_dir):
     """Rank 0 steps once; rank 1 connects its mailbox and then never sends: rank 0's launch must stop the handle."""
     import time

@@ -35,7 +35,7 @@ def audit(lines):
     start = next(i for i, l in enumerate(lines) if 'Inner Loop Header' in l)
     name = re.match(r'^(\.LBB\d+_\d+):', lines[start]).group(1)[2:]
     end = max(i for i, l in enumerate(lines) if re.search(r'in Loop: Header=' + name + r'\b', l))
-    while not lines[end + 1].startswith('.LBB') and 'Lfunc_end' not in lines[end + 1]:
+    while not lines[end + 1].startswith(('.LBB', '; %bb.')) and 'Lfunc_end' not in lines[end + 1]:     # the next block's header
         end += 1
     problems, slow = [], []
     # prologue: loads issued before the loop stay in flight until the loop consumes them
