@@ -523,6 +523,7 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
     // reductions like every cell (problem.py:342-347).  x edge e: ghost row ix = e ? Nx+1 : 0; its source row is the
     // partner row (periodic) or the adjacent one; y edges alike; corners are rule_y(rule_x(.)) as the reference's
     // x-then-y order produces them.
+#ifndef GPF_K2_NO_POSTPASS      // timing experiments only: results are wrong without it
     if (fused) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int src_row[2] = {x_periodic ? L.Nx : 1, x_periodic ? 1 : L.Nx};
@@ -604,6 +605,7 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
         }
         if (a.p2p.on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+#endif
 
     // ---- wave reduction: the record is valid in lane 0 ----
     for (int s = 32; s >= 1; s >>= 1) {
@@ -617,6 +619,9 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
         const double it = rcp(red.c2);
         red.c2 = (red.c2 == __builtin_inf()) ? 0.0 : P.e[6] * (it * it);
     }
+#ifdef GPF_K2_NO_POSTPASS
+    red.flags = 0;      // (timing experiment: keep stepping whatever the stale ghost cells do to the field)
+#endif
     result.ekin = red.ekin; result.v2 = red.v2; result.c2 = red.c2; result.mass = 0.0; result.flags = red.flags;
 }
 
@@ -657,6 +662,10 @@ __global__ __launch_bounds__(256, ((TOPO == 1 || TOPO == 3) ? GPF_K2_MINWAVES_LI
         }
         return;
     }
+#ifdef GPF_K2_NO_FINISH         // timing experiments only: block 0 commits its own record, nobody waits for anybody
+    if (blockIdx.x == 0 && threadIdx.x == 0) commit_step(a.st, own.ekin + 1.0, own.v2, own.c2, own.flags, a.log, a.log_base, a.log_cap);
+    return;
+#endif
     // ---- fused: one record per block; the last block to arrive folds them and commits the step ----
     // (the barrier below also puts every wave's drained stores -- message rows included -- before the arrival)
     if (lane == 0) red_sm[wv] = own;
