@@ -20,6 +20,7 @@ Extra objects on the JSON line:
 """
 import argparse
 import contextlib
+import ctypes
 import json
 import os
 import sys
@@ -229,11 +230,21 @@ def gp_variant(steps, n=2048, ntrain=512):
         prob._pre_run()
         prob.update()                                   # warm-up: first-use allocations, rocBLAS handle
         prob._scalars()
+
+        def passes():
+            launched, reused = (ctypes.c_int64 * 3)(), ctypes.c_int64()
+            assert prob._lib.gpf_gp_pass_counts(prob._h, launched, ctypes.byref(reused)) == 0
+            return list(launched), reused.value
+
+        p0, r0 = passes()
         t0 = time.perf_counter()
         for _ in range(steps):
             prob.update()
         sc = prob._scalars()                            # drains the stream
         t_step = (time.perf_counter() - t0) / steps
+        p1, r1 = passes()
+        p1[0] -= 1                                      # the pass of the closing _scalars() call is outside a step
+        per_step = [(b - a) / steps for a, b in zip(p0, p1)]
         assert sc.invalid == 0 and prob.step == steps + 1, "GP steps were skipped or went invalid"
         prob._gp_models['zz'].compute_variance(on_open_step=False)
         t0 = time.perf_counter()
@@ -241,8 +252,10 @@ def gp_variant(steps, n=2048, ntrain=512):
         t_var = time.perf_counter() - t0
         del prob
     cells = (n + 2)**2
-    evals = cells * ntrain * (2 * 3 + 1)                # model passes per step: 2 stages x 3 models + 1 sound speed
-    flops_mean = cells * ntrain * (2 * ((3 * 2 + 12) + 2 * (3 * 3 + 12)) + (3 * 2 + 12))
+    # passes actually launched per step: 2 stages x 3 models + 1 sound speed, minus the pressure evaluation the previous
+    # step's sound-speed pass already delivered (gpf_gp_pass_counts)
+    evals = cells * ntrain * sum(per_step)
+    flops_mean = cells * ntrain * (per_step[0] * (3 * 2 + 12) + (per_step[1] + per_step[2]) * (3 * 3 + 12))
     flops_var = cells * ntrain**2
     return {
         "workload": f"2D slider {n}x{n}, GP closures (pressure d=2, wall shear xz/yz d=3, Matern-3/2 ARD), {ntrain} training "
@@ -251,8 +264,10 @@ def gp_variant(steps, n=2048, ntrain=512):
         "matern_kernel_evaluations_per_s": evals / t_step,
         "roofline": {"bound": "fp64_valu", "achieved": flops_mean / t_step / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": flops_mean / t_step / 1e12 / FP64_PEAK_TFLOPS, "traffic": None,
-                     "kernel": "k_gp_mean (whole stage-wise step timed: ~95 % of it is the seven posterior-mean passes)",
-                     "algorithmic_flops_per_step": flops_mean},
+                     "kernel": "k_gp_mean (whole stage-wise step timed: ~95 % of it is the posterior-mean passes)",
+                     "algorithmic_flops_per_step": flops_mean,
+                     "posterior_mean_passes_per_step": {"pressure": per_step[0], "shear_xz": per_step[1], "shear_yz": per_step[2],
+                                                        "pressure_reused_from_sound_speed_pass": (r1 - r0) / steps}},
         "variance_pass": {"ms": t_var * 1e3, "model": "pressure",
                           "roofline": {"bound": "mfma_f64", "achieved": flops_var / t_var / 1e12, "peak": FP64_PEAK_TFLOPS,
                                        "unit": "TFLOP/s", "frac": flops_var / t_var / 1e12 / FP64_PEAK_TFLOPS, "traffic": None,

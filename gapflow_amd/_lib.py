@@ -106,6 +106,7 @@ SIGNATURES = {
                                    C.c_double, _DP, C.c_double, C.c_double]),
     'gpf_gp_clear_model': (C.c_int, [C.c_void_p, C.c_int]),
     'gpf_gp_variance': (C.c_int, [C.c_void_p, C.c_int, C.c_int, _DP]),
+    'gpf_gp_pass_counts': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }
 
 _lib = None

@@ -28,6 +28,11 @@ static int fail(int code, const std::string& msg) {
     return code;
 }
 
+// Common prologue of the C-ABI calls on a handle: select its device; unless the call only reads the state, forget what is
+// cached about it (gpf_handle::gp_state_mean).
+struct gpf_handle;
+static int enter(gpf_handle* h, bool reads_only = false);
+
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \
@@ -93,6 +98,17 @@ struct gpf_handle {
         bool has_linv = false;
         double xscale0 = 1.0;
     } gp[3];
+    // The sound-speed pass that closes a stage-wise step (d mean / d rho of the pressure surrogate on the new state) also
+    // leaves the posterior MEAN of that state here; the first closure evaluation of the next step -- same state, same model --
+    // copies it instead of running the pass again (one of seven posterior-mean passes per step).  Every C-ABI call except the
+    // ones that only read the state drops it (enter()).
+    double* gp_state_mean = nullptr;        // one plane
+    bool gp_state_mean_valid = false;
+    long long gp_state_mean_step = -1;      // the state's step count it belongs to
+    bool gp_state_mean_fresh = false;       // the pass has just written it (gpf_close_step decides whether it stands)
+    bool open_first_closures = false;       // gpf_stage_closures has not run yet in the open step
+    bool gp_reuse_state_mean = true;        // GPF_GP_NO_STATE_MEAN at gpf_create turns it off
+    long long gp_passes[3] = {0, 0, 0}, gp_reused = 0;
     double* gpvar = nullptr;                // 3 variance planes
     double* gpscratch = nullptr;            // block maxima + 4 result slots
     int gpscratch_n = 0;
@@ -114,6 +130,12 @@ struct gpf_handle {
     int nchunks2 = 0, nblocks2 = 0, npartials2_cap = 0, nblock_partials_cap = 0;
     bool plan2_valid = false;
 };
+
+static int enter(gpf_handle* h, bool reads_only) {
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (!reads_only) h->gp_state_mean_valid = false;
+    return GPF_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 static void make_phys(const gpf_config& c, Phys& P) {
@@ -204,6 +226,7 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
     }
     h->E.halo[0] = cfg->halo_lo; h->E.halo[1] = cfg->halo_hi;
     h->split_edges = std::getenv("GPF_STEP_UNFUSED_EDGES") != nullptr;
+    h->gp_reuse_state_mean = std::getenv("GPF_GP_NO_STATE_MEAN") == nullptr;
     make_phys(*cfg, h->P);
 
     const size_t plane_b = (size_t)L.plane * sizeof(double);
@@ -243,7 +266,7 @@ extern "C" int gpf_destroy(gpf_handle* h) {
     if (!h) return GPF_OK;
     hipSetDevice(h->cfg.device);
     void* ptrs[] = {h->q[0], h->q[1], h->topo, h->topo_line, h->Ls, h->g1, h->seam, h->halo, h->beyond, h->st, h->partials, h->arrive, h->block_partials, h->spart,
-                    h->log, h->stage, h->fields, h->work, h->gpvar, h->gpscratch, h->gptile,
+                    h->log, h->stage, h->fields, h->work, h->gpvar, h->gp_state_mean, h->gpscratch, h->gptile,
                     h->gp[0].Z, h->gp[0].alpha, h->gp[0].L, h->gp[1].Z, h->gp[1].alpha, h->gp[1].L,
                     h->gp[2].Z, h->gp[2].alpha, h->gp[2].L, h->gp[0].Linv, h->gp[1].Linv, h->gp[2].Linv};
     if (h->blas && roclibs().ok) roclibs().destroy(h->blas);
@@ -300,7 +323,7 @@ static int ensure_fields(gpf_handle* h) {
 
 extern "C" int gpf_upload(gpf_handle* h, int field, const double* host, size_t count) {
     if (!h || !host) return fail(GPF_ERR_INVALID, "gpf_upload: null argument");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    GPF_TRY(enter(h));
     const Layout& L = h->L;
     const int nc = field_ncomp(field);
     if (field != GPF_FIELD_Q && field != GPF_FIELD_TOPO && field != GPF_FIELD_EXTRA)
@@ -365,7 +388,7 @@ extern "C" int gpf_upload(gpf_handle* h, int field, const double* host, size_t c
 
 extern "C" int gpf_download(gpf_handle* h, int field, double* host, size_t count) {
     if (!h || !host) return fail(GPF_ERR_INVALID, "gpf_download: null argument");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    GPF_TRY(enter(h, true));
     const Layout& L = h->L;
     const int nc = field_ncomp(field);
     if (nc == 0) return fail(GPF_ERR_INVALID, "gpf_download: unknown field id");
@@ -417,7 +440,8 @@ static const double* beyond_rows(gpf_handle* h, const double* q) {
     return h->beyond + (working ? 2 * h->L.pitch : 0);
 }
 
-static int launch_fields(gpf_handle* h, const double* q) {
+// `pressure_mean_cached`: the pressure surrogate's mean of this very field is in gp_state_mean (see gpf_handle)
+static int launch_fields(gpf_handle* h, const double* q, bool pressure_mean_cached = false) {
     GPF_TRY(ensure_fields(h));
     const Layout& L = h->L;
     const long long n = (long long)(L.Nx + 2) * (L.Ny + 2);
@@ -434,15 +458,20 @@ static int launch_fields(gpf_handle* h, const double* q) {
         else hipLaunchKernelGGL((k_fields<EOS_, false>), dim3(blocks_for(n)), dim3(256), 0, h->stream, q, h->topo, (const double*)nullptr, F, L, h->P);
     });
     HIP_TRY(hipGetLastError());
-    for (int w = 0; w < 3; ++w)
-        if (h->gp[w].set) GPF_TRY(gp_launch_mean(h, w, q, false, nullptr));
+    for (int w = 0; w < 3; ++w) {
+        if (!h->gp[w].set) continue;
+        if (w == 0 && pressure_mean_cached) {
+            HIP_TRY(hipMemcpyAsync(F.p, h->gp_state_mean, (size_t)L.plane * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            h->gp_reused += 1;
+        } else GPF_TRY(gp_launch_mean(h, w, q, false, nullptr));
+    }
     return GPF_OK;
 }
 
 extern "C" int gpf_update_closures(gpf_handle* h) {
     if (!h) return fail(GPF_ERR_INVALID, "null handle");
     if (!h->has_q || !h->has_topo) return fail(GPF_ERR_STATE, "gpf_update_closures: upload q and topography first");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    GPF_TRY(enter(h));
     int par = 0;
     GPF_TRY(current_parity(h, &par));
     GPF_TRY(launch_fields(h, h->q[par]));
@@ -482,15 +511,21 @@ static void fill_scalars(const StepState& s, const ScalarPartial* sp, double dxd
 extern "C" int gpf_scalars(gpf_handle* h, gpf_scalars_t* out) {
     if (!h || !out) return fail(GPF_ERR_INVALID, "gpf_scalars: null argument");
     if (!h->has_q || !h->has_topo) return fail(GPF_ERR_STATE, "gpf_scalars: upload q and topography first");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    GPF_TRY(enter(h, true));
     int par = 0;
     GPF_TRY(current_parity(h, &par));
     ScalarPartial* tot = h->spart + h->nspart;
+    h->gp_state_mean_fresh = false;
     GPF_TRY(launch_scalars(h, h->q[par], tot));
     ScalarPartial sp; StepState s;
     HIP_TRY(hipMemcpyAsync(&sp, tot, sizeof(sp), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(&s, h->st, sizeof(s), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->gp_state_mean_fresh && s.parity == par) {        // the sound-speed pass ran on the committed state
+        h->gp_state_mean_valid = true;
+        h->gp_state_mean_step = s.step;
+    }
+    h->gp_state_mean_fresh = false;
     fill_scalars(s, &sp, h->cfg.dx * h->cfg.dy, out);
     return GPF_OK;
 }
@@ -527,7 +562,7 @@ extern "C" int gpf_set_dt(gpf_handle* h, double dt) {
 extern "C" int gpf_pre_run(gpf_handle* h) {
     if (!h) return fail(GPF_ERR_INVALID, "null handle");
     if (!h->has_q || !h->has_topo) return fail(GPF_ERR_STATE, "gpf_pre_run: upload q and topography first");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    GPF_TRY(enter(h));
     gpf_scalars_t sc;
     GPF_TRY(gpf_scalars(h, &sc));
     StepState s;
@@ -801,7 +836,7 @@ extern "C" int gpf_step(gpf_handle* h, int64_t n, int honor_stop, gpf_scalars_t*
     if (h->cfg.thinning != GPF_THINNING_NONE)
         return fail(GPF_ERR_STATE, "gpf_step: shear thinning needs grad p (a wider stencil than the fused step has); use the stage-wise calls");
     if (n < 0) return fail(GPF_ERR_INVALID, "gpf_step: n < 0");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    GPF_TRY(enter(h));
     int64_t done = 0, logged = 0;
     const bool small = small_grid_eligible(h);
     while (done < n) {
@@ -834,7 +869,7 @@ extern "C" int gpf_step_timed(gpf_handle* h, int64_t n, double* kernel_ms, doubl
     if (!h || !kernel_ms || !total_ms) return fail(GPF_ERR_INVALID, "gpf_step_timed: null argument");
     if (!h->pre_run_done) return fail(GPF_ERR_STATE, "gpf_step_timed: call gpf_pre_run first");
     if (n < 1 || n > h->log_cap) return fail(GPF_ERR_INVALID, "gpf_step_timed: 1 <= n <= 4096");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    GPF_TRY(enter(h));
     std::vector<hipEvent_t> ev(2 * n + 2);
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipEventRecord(ev[2 * n], h->stream));

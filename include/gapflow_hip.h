@@ -277,6 +277,12 @@ int gpf_gp_clear_model(gpf_handle* h, int which);
  * the GPF_FIELD_*_VAR field (times yscale^2); *max_var = its maximum (the active-learning criterion,
  * gp.py:408).  on_open_step != 0: evaluate on the working field of an open step. */
 int gpf_gp_variance(gpf_handle* h, int which, int on_open_step, double* max_var);
+/* Posterior-mean passes over the grid since gpf_create: launched[which] per model, and *reused = evaluations of the
+ * pressure surrogate that were served by the pass that closed the previous step (stress.py:533-537 evaluates the
+ * sound speed -- the slope of the mean -- on the state the next step's first closure update, stress.py:522-531, sees
+ * again: one kernel launch yields both).  Introspection for tests and bench.py; GPF_GP_NO_STATE_MEAN=1 at gpf_create
+ * turns the reuse off. */
+int gpf_gp_pass_counts(gpf_handle* h, int64_t launched[3], int64_t* reused);
 
 /* Diagnostic: time of one pass of an elementwise kernel that reads `nin` and writes `nout` fp64 planes of
  * `doubles_per_plane` elements (16 bytes per lane, grid-stride): what THIS device streams for the byte count of a fused

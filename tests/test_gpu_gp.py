@@ -139,6 +139,47 @@ def test_gp_steps_match_oracle(hiplib):
     assert prob.step == ref.step == 5
 
 
+def _pass_counts(prob):
+    launched, reused = (C.c_int64 * 3)(), C.c_int64()
+    assert prob._lib.gpf_gp_pass_counts(prob._h, launched, C.byref(reused)) == 0
+    return list(launched), reused.value
+
+
+def test_sound_speed_pass_serves_the_next_steps_first_pressure_evaluation(hiplib, monkeypatch):
+    """The pass that closes a step (slope of the pressure surrogate's mean on the new state, stress.py:533-537) also keeps
+    the mean; the next step's first closure update (same state, same model) copies it: six posterior-mean passes per step
+    instead of seven, the same field bit for bit as with the reuse switched off, and no reuse across a model change."""
+    prob, _ = build()
+    monkeypatch.setenv('GPF_GP_NO_STATE_MEAN', '1')
+    plain, _ = build()
+    monkeypatch.delenv('GPF_GP_NO_STATE_MEAN')
+    l0, r0 = _pass_counts(prob)
+    p0, _ = _pass_counts(plain)
+    nsteps = 6
+    for _ in range(nsteps):
+        prob.update()
+        plain.update()
+    l1, r1 = _pass_counts(prob)
+    p1, pr = _pass_counts(plain)
+    assert pr == 0 and p1[0] - p0[0] == 3 * nsteps and p1[1] - p0[1] == 2 * nsteps == p1[2] - p0[2]
+    assert r1 - r0 >= nsteps - 1 and (l1[0] - l0[0]) + (r1 - r0) == 3 * nsteps      # pressure: 2 launched + 1 reused per step
+    assert l1[1] - l0[1] == 2 * nsteps == l1[2] - l0[2]
+    assert np.array_equal(prob.q, plain.q) and prob.dt == plain.dt
+    # a refit in between (active learning does this) must not be served from the old model's mean
+    for pb in (prob, plain):
+        m = pb._gp_models['zz']
+        m.theta = m.theta + 0.05
+        m.attach()
+    before, rb = _pass_counts(prob)
+    prob.update()
+    plain.update()
+    after, ra = _pass_counts(prob)
+    assert ra == rb and after[0] - before[0] == 3          # nothing reused in the step after the refit
+    assert np.array_equal(prob.q, plain.q)
+    prob.update()
+    assert _pass_counts(prob)[1] == ra + 1                  # ... and reuse resumes with the step after
+
+
 def test_predict_repredict_self_consistency(hiplib):
     """tests/test_inference.py:88-111 of the reference: a fresh prediction equals the cached re-prediction."""
     prob, _ = build()
