@@ -147,6 +147,12 @@ static int blocks_for(long long n, int bs = 256, int cap = 4096) {
     return (int)std::max<long long>(1, std::min<long long>(b, cap));
 }
 
+#ifdef GPF_ONLY_EOS_DH   // experiment builds (tools/ab_step.py variants): one equation of state, a seventh of the compile time
+#define EOS_DISPATCH(eos, ...)                                                                          \
+    do {                                                                                                \
+        if ((eos) == GPF_EOS_DH) { constexpr int EOS_ = EOS_DH; __VA_ARGS__; }      /* gpf_create refuses the others */ \
+    } while (0)
+#else
 #define EOS_DISPATCH(eos, ...)                                                                          \
     switch (eos) {                                                                                      \
     case GPF_EOS_DH: { constexpr int EOS_ = EOS_DH; __VA_ARGS__; } break;                              \
@@ -157,6 +163,7 @@ static int blocks_for(long long n, int bs = 256, int cap = 4096) {
     case GPF_EOS_BWR: { constexpr int EOS_ = EOS_BWR; __VA_ARGS__; } break;                            \
     default: { constexpr int EOS_ = EOS_BAYADA; __VA_ARGS__; } break;                                  \
     }
+#endif
 
 // slip-length field x piezo-viscosity: the edge kernels are specialised like the step kernel they serve
 #define LS_PIEZO_DISPATCH(ls, pz, ...)                                                                  \
@@ -208,6 +215,9 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
             return fail(GPF_ERR_INVALID, "gpf_create: an edge must be periodic for all components or for none "
                                          "(problem.py:682-707 applies the periodic copy only when all three are 'P')");
     }
+#ifdef GPF_ONLY_EOS_DH
+    if (cfg->eos != GPF_EOS_DH) return fail(GPF_ERR_INVALID, "gpf_create: this build (-DGPF_ONLY_EOS_DH) holds the Dowson-Higginson kernels only");
+#endif
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(GPF_ERR_NO_DEVICE, "gpf_create: no HIP device visible (this library has no CPU path)");
@@ -650,8 +660,11 @@ static Strip2Geom strip2_geom(const Layout& L, int D) {
 // slab).  GPF_STEP_UNFUSED_EDGES=1 at gpf_create selects the older split form instead, kept as a cross-check.
 static bool step2_fused(const gpf_handle* h) { return !h->split_edges; }
 
+constexpr int K2_LONG_MARCH_ROWS = 100;    // rows per wave from which plan_step2 runs one wave per SIMD instead of two
+
 // One wave marches over one row chunk of one 126-column strip; the chunks are sized so that all waves are resident at
-// once (a single round, no tail) when the problem is big enough.
+// once (a single round, no tail) when the problem is big enough: two waves per SIMD, or one where that still leaves
+// long marches.
 static int plan_step2(gpf_handle* h) {
     if (h->plan2_valid) return GPF_OK;
     const Layout& L = h->L;
@@ -666,6 +679,11 @@ static int plan_step2(gpf_handle* h) {
         HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->cfg.device));
         const int resident_waves = std::max(1, per_cu * ncu) * 4;
         nchunks = resident_waves / nstrips;
+        // Long marches run better with ONE wave per SIMD (half as many concurrent row streams into HBM, half the halo rows;
+        // the rows in flight ahead of each wave cover the latency alone): 3 % at 4096^2 (132 rows per wave) and at 6144^2,
+        // nothing at 3072^2 (76 rows), a loss below that (profiles/r02_ab_history.md).
+        const int one_per_simd = (ncu * 4) / nstrips;
+        if (one_per_simd >= 1 && L.Nx / one_per_simd >= K2_LONG_MARCH_ROWS) nchunks = one_per_simd;
     }
     nchunks = std::max(1, std::min(nchunks, std::max(1, L.Nx / 4)));        // small grids: >= 4 rows per chunk
     h->nchunks2 = nchunks;

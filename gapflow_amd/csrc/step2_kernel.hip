@@ -36,7 +36,14 @@ namespace gpf {
 
 constexpr int STRIP2 = 126;     // output columns per wavefront
 #ifndef GPF_K2_AHEAD
-#define GPF_K2_AHEAD 2          // rows requested ahead of the one being computed (1 or 2)
+#define GPF_K2_AHEAD 2          // rows requested ahead of the one being computed (1 .. 4)
+#endif
+#ifndef GPF_K2_AHEAD_LINE
+#define GPF_K2_AHEAD_LINE 4     // ... for the x-only-gap kernels: three loads per row instead of six, so two rows ahead keep only
+                                // 6 KB per wave in flight -- with one wave per SIMD (long marches, plan_step2) less than the
+                                // bandwidth-latency product; 4 rows measured 1.7 % faster there, equal elsewhere.  (3 is unusable:
+                                // with four row buffers hipcc renames them across the back edge and copies registers whose
+                                // loads are in flight -- tools/audit_step_isa.py reports it.)
 #endif
 #ifndef GPF_K2_MINWAVES
 #define GPF_K2_MINWAVES 2       // waves per SIMD the register allocation is held to
@@ -270,7 +277,7 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
         if (HAS_LS) asm_load16(r.ls[0], (dummy ? lane_q : lane_ls) + rb);
     };
     // wait until row r has landed: exactly AHEAD row requests (NL loads each) have been issued after it
-    constexpr int AHEAD_ROWS = PIEZO ? 1 : GPF_K2_AHEAD;
+    constexpr int AHEAD_ROWS = PIEZO ? 1 : ((TOPO == 1 || TOPO == 3) ? GPF_K2_AHEAD_LINE : GPF_K2_AHEAD);
     auto arrive = [&](Raw& r) {
         asm_wait3<AHEAD_ROWS * NL>(r.q[0], r.q[1], r.q[2]);
         if (TOPO == 0) asm_wait3<AHEAD_ROWS * NL>(r.t[0], r.t[1], r.t[2]);
@@ -376,10 +383,14 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
     // HBM round trip).  AHEAD + 1 row buffers rotate by NAME: the loop body is a lambda instantiated once per
     // buffer, so no register copies are needed to advance the window.
     // (the piezo-viscosity closures -- exp / pow per cell -- leave no registers for the third buffer: one row ahead there)
-    constexpr int AHEAD = PIEZO ? 1 : GPF_K2_AHEAD;
-    Raw rowbuf[AHEAD + 1];
+    constexpr int AHEAD = AHEAD_ROWS;
+    static_assert(AHEAD >= 1 && AHEAD <= 4, "1 to 4 rows ahead");
+    constexpr int NB = AHEAD + 1;
+    Raw rowbuf[NB];
     issue(n_first - 1, rowbuf[0]);
-    if (AHEAD == 2) issue(n_first, rowbuf[1]);
+    if (AHEAD >= 2) issue(n_first, rowbuf[1 % NB]);
+    if (AHEAD >= 3) issue(n_first + 1, rowbuf[2 % NB]);
+    if (AHEAD >= 4) issue(n_first + 2, rowbuf[3 % NB]);
 
     // carried from the previous row, per slot
     double fx1p[2][3] = {{0, 0, 0}, {0, 0, 0}};     // stage-1 x-flux of row n-1
@@ -507,7 +518,9 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
     for (int n = n_first - 1;;) {
         march(n, rowbuf[0], rowbuf[AHEAD]); if (++n > n_last + 1) break;
         march(n, rowbuf[1], rowbuf[0]); if (++n > n_last + 1) break;
-        if (AHEAD == 2) { march(n, rowbuf[2 % (AHEAD + 1)], rowbuf[1]); if (++n > n_last + 1) break; }
+        if (AHEAD >= 2) { march(n, rowbuf[2 % NB], rowbuf[1]); if (++n > n_last + 1) break; }
+        if (AHEAD >= 3) { march(n, rowbuf[3 % NB], rowbuf[2 % NB]); if (++n > n_last + 1) break; }
+        if (AHEAD >= 4) { march(n, rowbuf[4 % NB], rowbuf[3 % NB]); if (++n > n_last + 1) break; }
     }
     // The last requests (repeats of the final row) are still in flight: drain them while the buffers are still
     // live, or a late return would land in registers the code below has reused.

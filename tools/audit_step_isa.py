@@ -1,6 +1,6 @@
 """ISA audit of k_step2's hand-pipelined row loads (csrc/step2_kernel.hip), on the CPU (hipcc cross-compiles):
 
-    python tools/audit_step_isa.py
+    python tools/audit_step_isa.py [--all]
 
 The row loads are inline-asm `global_load_dwordx4`; hipcc treats their destination registers as written when the asm
 statement ends, so it could legally copy, spill or reuse them before the data has landed (CDNA4 guide 5.7, item 1).  For
@@ -18,8 +18,9 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'gapflow_amd', 'csrc')
-VARIANTS = ['0, false, false, 1, 0', '0, false, false, -1, 0', '0, false, false, 1, 1', '0, false, false, 1, 2',
-            '0, false, false, 1, 3', '0, true, false, 1, 0', '0, false, true, 1, 0', '5, true, true, -1, 0']
+VARIANTS = ['0, false, false, 1, 0', '0, false, false, -1, 0', '0, false, false, 1, 1', '0, false, false, -1, 1', '0, false, false, 1, 2',
+            '0, false, false, 1, 3', '0, false, false, -1, 3', '2, false, false, 1, 3', '5, false, false, -1, 3', '0, true, false, 1, 0',
+            '0, false, true, 1, 0', '5, true, true, -1, 0']
 
 
 def regs_of(tok):
@@ -77,7 +78,7 @@ def audit(lines):
     waits = [next(idx for idx, kind, _ in events if kind == 'wait' and idx > g[0][0]) for g in groups]
     n = len(groups)
     for k, loads in enumerate(groups):
-        target = waits[(k + 2) % n] if n == 3 else waits[(k + 1) % n]
+        target = waits[(k + n - 1) % n]         # a row is consumed n - 1 = AHEAD loop bodies after its request
         for gidx, regs in loads:
             span = [(i, r) for i, kind, r in events if kind == 'ins' and (gidx < i < target if target > gidx else (i > gidx or i < target))]
             for i, r in span:
@@ -87,15 +88,19 @@ def audit(lines):
 
 
 def main():
+    everything = '--all' in sys.argv        # every instantiation of the shipped library (compiles api.hip: minutes)
     with tempfile.TemporaryDirectory() as tmp:
         src = os.path.join(tmp, 't.hip')
         with open(src, 'w') as f:
-            f.write('#include <hip/hip_runtime.h>\n#include "step_kernel.hip"\n#include "aux_kernels.hip"\n#include "step2_kernel.hip"\nusing namespace gpf;\n')
-            for v in VARIANTS:
-                f.write(f'template __global__ void gpf::k_step2<{v}>(const Step2Args, const Phys);\n')
+            if everything:
+                f.write('#include "api.hip"\n')
+            else:
+                f.write('#include <hip/hip_runtime.h>\n#include "step_kernel.hip"\n#include "aux_kernels.hip"\n#include "step2_kernel.hip"\nusing namespace gpf;\n')
+                for v in VARIANTS:
+                    f.write(f'template __global__ void gpf::k_step2<{v}>(const Step2Args, const Phys);\n')
         asm = os.path.join(tmp, 't.s')
         subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=fast', '-I', CSRC, '-S',
-                        '--cuda-device-only', src, '-o', asm], check=True, capture_output=True)
+                        '--cuda-device-only', src, '-o', asm] + os.environ.get('GPF_EXTRA_FLAGS', '').split(), check=True, capture_output=True)
         text = open(asm).read().split('\n')
     bad = 0
     starts = [i for i, l in enumerate(text) if re.match(r'^_ZN3gpf7k_step2I.*:', l)]
