@@ -43,7 +43,8 @@ def main():
             d = json.loads(out.stdout.strip().splitlines()[-1])
             v = d['variants']['asperity_gap_2d_V0.05']
             res[name].append((d['roofline']['kernel_ms'], d['ms_per_step'], v['kernel_ms'], v['ms_per_step']))
-            print(f"round {r} {name:>12}: line kernel {d['roofline']['kernel_ms']*1e3:7.1f} step {d['ms_per_step']*1e3:7.1f} us | "
+            ceil = d['roofline'].get('stream_ceiling_GBps', 0.0), v['roofline'].get('stream_ceiling_GBps', 0.0)
+            print(f"round {r} {name:>12}: [box streams {ceil[0]:.0f} / {ceil[1]:.0f} GB/s] line kernel {d['roofline']['kernel_ms']*1e3:7.1f} step {d['ms_per_step']*1e3:7.1f} us | "
                   f"2-D gap kernel {v['kernel_ms']*1e3:7.1f} step {v['ms_per_step']*1e3:7.1f} us", flush=True)
     print('--- medians (us) ---')
     for name, rows in res.items():
