@@ -32,28 +32,18 @@ def regs_of(tok):
     return out
 
 
-def audit(lines):
-    start = next(i for i, l in enumerate(lines) if 'Inner Loop Header' in l)
+def loop_span(lines, start):
     name = re.match(r'^(\.LBB\d+_\d+):', lines[start]).group(1)[2:]
-    end = max(i for i, l in enumerate(lines) if re.search(r'in Loop: Header=' + name + r'\b', l))
+    end = max([i for i, l in enumerate(lines) if re.search(r'in Loop: Header=' + name + r'\b', l)] + [start])
     while not lines[end + 1].startswith(('.LBB', '; %bb.')) and 'Lfunc_end' not in lines[end + 1]:     # the next block's header
         end += 1
-    problems, slow = [], []
-    # prologue: loads issued before the loop stay in flight until the loop consumes them
-    inflight, in_asm = set(), False
-    for i, l in enumerate(lines[:start]):
-        t = l.strip()
-        if t.startswith(';;#ASMSTART'):
-            in_asm = True
-        elif t.startswith(';;#ASMEND'):
-            in_asm = False
-        elif in_asm and t.startswith('global_load_dwordx4'):
-            inflight |= regs_of(t.split(',')[0])
-        elif not in_asm and t and t[0] not in ';.' and inflight and regs_of(t) & inflight:
-            problems.append(f'prologue line {i}: {t}')
-    body = lines[start:end + 1]
+    return end
+
+
+def asm_events(block):
+    """(index, kind, registers) of a block: 'load' / 'wait' inside inline asm, 'ins' for compiler instructions."""
     events, in_asm = [], False
-    for i, l in enumerate(body):
+    for i, l in enumerate(block):
         t = l.strip()
         if t.startswith(';;#ASMSTART'):
             in_asm = True
@@ -65,26 +55,67 @@ def audit(lines):
             events.append((i, 'wait', set()))
         elif not in_asm and t and t[0] not in ';.':
             events.append((i, 'ins', regs_of(t)))
-            if t.startswith('scratch_') or t.startswith('global_load') or t.startswith('buffer_load'):
-                slow.append(f'loop line {i}: compiler-visible memory access {t}')
-    groups, cur = [], None
-    for idx, kind, regs in events:
+    return events
+
+
+def audit(lines):
+    """Every march loop of the function (the kernel holds one per compile-time flavour of the march, entered from a common
+    prologue): returns (row-load groups per loop, register hazards, compiler-visible memory accesses inside the loops)."""
+    headers = [i for i, l in enumerate(lines) if 'Inner Loop Header' in l]
+    loops = [(h, loop_span(lines, h)) for h in headers]
+    loops = [(h, e) for h, e in loops if any(k == 'load' for _, k, _ in asm_events(lines[h:e + 1]))]
+    problems, slow, ngroups = [], [], []
+    first = loops[0][0]
+    # the prologue's loads stay in flight until a loop consumes them: nothing before the loops may touch their registers
+    inflight = set()
+    for i, kind, regs in asm_events(lines[:first]):
         if kind == 'load':
-            cur = cur or []
-            cur.append((idx, regs))
-        elif kind == 'wait' and cur:
-            groups.append(cur)
-            cur = None
-    waits = [next(idx for idx, kind, _ in events if kind == 'wait' and idx > g[0][0]) for g in groups]
-    n = len(groups)
-    for k, loads in enumerate(groups):
-        target = waits[(k + n - 1) % n]         # a row is consumed n - 1 = AHEAD loop bodies after its request
-        for gidx, regs in loads:
-            span = [(i, r) for i, kind, r in events if kind == 'ins' and (gidx < i < target if target > gidx else (i > gidx or i < target))]
-            for i, r in span:
-                if r & regs:
-                    problems.append(f'loop line {i}: touches in-flight v{sorted(r & regs)}: {body[i].strip()}')
-    return n, problems, slow
+            inflight |= regs
+        elif kind == 'ins' and regs & inflight:
+            problems.append(f'prologue line {i}: {lines[i].strip()}')
+    prev_end = first - 1
+    for h, e in loops:
+        # straight-line code between the previous loop and this one (this loop's pre-header, the other loop's exit path)
+        for i, kind, regs in asm_events(lines[prev_end + 1:h]):
+            if kind == 'wait':
+                break                       # the post-loop drain: nothing is in flight beyond it
+            if kind == 'ins' and regs & inflight:
+                problems.append(f'line {prev_end + 1 + i} (between loops): {lines[prev_end + 1 + i].strip()}')
+        body = lines[h:e + 1]
+        events = asm_events(body)
+        for i, kind, regs in events:
+            t = body[i].strip()
+            if kind == 'ins' and (t.startswith('scratch_') or t.startswith('global_load') or t.startswith('buffer_load')):
+                slow.append(f'loop line {i}: compiler-visible memory access {t}')
+        groups, cur = [], None
+        for idx, kind, regs in events:
+            if kind == 'load':
+                cur = cur or []
+                cur.append((idx, regs))
+            elif kind == 'wait' and cur:
+                groups.append(cur)
+                cur = None
+        waits = [next(idx for idx, kind, _ in events if kind == 'wait' and idx > g[0][0]) for g in groups]
+        n = len(groups)
+        ngroups.append(n)
+        bufregs = set()
+        for k, loads in enumerate(groups):
+            target = waits[(k + n - 1) % n]         # a row is consumed n - 1 = AHEAD loop bodies after its request
+            for gidx, regs in loads:
+                bufregs |= regs
+                span = [(i, r) for i, kind, r in events if kind == 'ins' and (gidx < i < target if target > gidx else (i > gidx or i < target))]
+                for i, r in span:
+                    if r & regs:
+                        problems.append(f'loop line {i}: touches in-flight v{sorted(r & regs)}: {body[i].strip()}')
+        # after the loop: the last (dummy) requests are in flight until the hand-written drain
+        for i, kind, regs in asm_events(lines[e + 1:e + 400]):
+            if kind == 'wait':
+                break
+            if kind == 'ins' and regs & bufregs and not lines[e + 1 + i].strip().startswith(('s_', ';')):
+                problems.append(f'line {e + 1 + i} (loop exit, before the drain): {lines[e + 1 + i].strip()}')
+        inflight |= bufregs
+        prev_end = e
+    return ngroups, problems, slow
 
 
 def main():
@@ -107,7 +138,7 @@ def main():
     for a in starts:
         b = next(i for i in range(a, len(text)) if text[i].startswith('.Lfunc_end'))
         n, problems, slow = audit(text[a:b])
-        print(text[a].split(':')[0], f'{n} row-load groups in the march,', 'registers safe' if not problems else f'{len(problems)} REGISTER HAZARDS',
+        print(text[a].split(':')[0], f'{"+".join(map(str, n))} row-load groups in the march loop(s),', 'registers safe' if not problems else f'{len(problems)} REGISTER HAZARDS',
               '' if not slow else f'; {len(slow)} compiler-visible memory accesses in the loop (spills: slow, not wrong)')
         for p in problems[:10]:
             print('   ', p)
