@@ -277,9 +277,10 @@ def gp_variant(steps, n=2048, ntrain=512):
 
 
 def run_slabs(args, rank, world):
-    """N x-slabs, one rank per GPU.  The same K steps are timed up to three times: host-dispatched with one RCCL
-    all-gather per step (the conservative transport), with the peer-to-peer mailbox transport, and with the all-gather
-    steps replayed from a hipGraph.  Rank 0 reports the fastest run that completed and reproduced the first one."""
+    """N x-slabs, one rank per GPU: K steps, host-dispatched, one RCCL all-gather per step (the conservative transport).
+    Opt-in (GPF_BENCH_TRY_P2P=1 / GPF_BENCH_TRY_GRAPH=1) the same K steps are timed again with the peer-to-peer mailbox
+    transport and with the all-gather steps replayed from a hipGraph; rank 0 then reports the fastest run that completed
+    and reproduced the first one, and a failed attempt makes the process exit non-zero."""
     import threading
     import torch
     import torch.distributed as dist
@@ -303,7 +304,7 @@ def run_slabs(args, rank, world):
         return float(w.item())
 
     def line(wall, mode):
-        per_gpu = BYTES_PER_CELL * cells * args.steps / wall / 1e9 / world
+        per_gpu = BYTES_PER_CELL_LINE * cells * args.steps / wall / 1e9 / world     # x-only gap: 48 B per cell-update
         return {
             "metric": "Mcell-updates/s (fp64), 4096^2 grid", "value": cells * args.steps / wall / 1e6,
             "unit": "Mcell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
