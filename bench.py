@@ -271,8 +271,11 @@ def gp_variant(steps, n=2048, ntrain=512):
         "variance_pass": {"ms": t_var * 1e3, "model": "pressure",
                           "roofline": {"bound": "mfma_f64", "achieved": flops_var / t_var / 1e12, "peak": FP64_PEAK_TFLOPS,
                                        "unit": "TFLOP/s", "frac": flops_var / t_var / 1e12 / FP64_PEAK_TFLOPS, "traffic": None,
-                                       "kernel": "k_gp_ks_tile + rocBLAS dgemm (L^-1 Ks) + k_gp_var_tile, 64 MiB tiles",
-                                       "algorithmic_flops_per_pass": flops_var}},
+                                       "kernel": "k_gp_var_fused: Matern values through LDS, L^-1 Ks on v_mfma_f64_16x16x4_f64 "
+                                                 "(triangular: 52 % of the square product issued), column norms in registers",
+                                       "algorithmic_flops_per_pass": flops_var,
+                                       "note": "algorithmic flops = cells * N^2 (the triangular product); on gfx950 fp64 VALU work "
+                                               "shares the f64 MFMA units, so the Matern evaluations are not hidden"}},
     }
 
 

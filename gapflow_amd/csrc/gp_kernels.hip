@@ -233,6 +233,132 @@ __global__ __launch_bounds__(1024) void k_gp_var_tile(const double* V, int n, in
     }
 }
 
+// Predictive variance in ONE kernel, nothing through HBM: var_j = (A - |L^-1 k(Z, z*_j)|^2) * yscale^2 for n <= 512.
+// The tiled path above writes a 64-MiB Ks tile, reads it back in the product, writes the product and reads that back for
+// the column norms: 290 MB of HBM traffic per 16 K cells next to 2 x 17 MFLOP per cell.  Here a workgroup of 16 waves owns
+// 64 cells:
+//   * the Matern values k(Z_k, z*_j) of 32 training points x 64 cells at a time are produced on the vector ALUs straight
+//     into LDS (each wave: its lane's cell against 2 wave-uniform training points, 2 evaluations per lane and batch),
+//     double-buffered, one barrier per batch;
+//   * V = L^-1 Ks runs on the matrix cores (v_mfma_f64_16x16x4_f64; A operand = L^-1 rows straight from L2 -- the 2 MB
+//     factor stays resident there --, B operand = the LDS tile, accumulators never leave the registers).  L^-1 is lower
+//     triangular: a 16-row tile t has nothing to multiply beyond column 16 t + 15.  Wave w owns tiles w and 31 - w: 52 % of
+//     the square product's flops, the same amount for every wave;
+//   * the column norms are the sum of squares of the accumulators: over the registers, across the four lane groups that
+//     hold different rows of the same column (layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 reg), then
+//     over the waves in a fixed order through LDS (deterministic).
+// Lane maps of the operands: A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15], one f64 each.
+// Measured (2048^2 cells x 512 points): 26.5 ms against 39.5 ms for the tiled path.  571 M MFMAs at 64 cycles each are
+// 14.9 ms of matrix-pipe time (SQ_VALU_MFMA_BUSY_CYCLES); the rest cannot hide behind them: on this chip the f64 matrix
+// instruction and the f64 vector ALU are the same units -- every fp64 VALU instruction between two MFMAs lengthens the pair
+// by its own 4+ cycles (tools/mfma_f64_probe.hip: 78 TFLOP/s with nothing in between, 55 with six FMAs, 43 with twelve) --
+// so the Matern values (40 fp64 instructions each) and the operand selects are paid in full.  Tried and dropped: 8 waves
+// with four tiles each (250 registers; prefetched or not: 27-30 ms), 64-column batches (no change), unconditional
+// prefetched A loads in straight-line half batches (exact s_waitcnt counts, but 128 registers per wave at 16 waves per
+// workgroup do not hold them: scratch spills, 93 ms).
+constexpr int GPV_CELLS = 64, GPV_KB = 32, GPV_MAX_N = 512;
+constexpr int GPV_WAVES = 16;                       // waves per workgroup
+constexpr int GPV_TPW = 32 / GPV_WAVES;             // 16-row tiles of L^-1 per wave
+typedef double gpv_acc __attribute__((ext_vector_type(4)));
+
+template <int D>
+__global__ __launch_bounds__(64 * GPV_WAVES) void k_gp_var_fused(const GpModelDev g, const double* __restrict__ Linv, const GpFieldArgs a,
+                                                                 double yscale2, double* __restrict__ var_plane, double* __restrict__ blockmax) {
+    __shared__ double Bs[2][GPV_KB][GPV_CELLS];
+    __shared__ double part[GPV_WAVES][GPV_CELLS];
+    const int n = g.n;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long w = a.L.Ny + 2, ncell = (long long)(a.L.Nx + 2) * w;
+    const long long cell = blockIdx.x * (long long)GPV_CELLS + lane;
+    const bool cell_ok = cell < ncell;
+    const long long o = cell_ok ? a.L.at((int)(cell / w), (int)(cell % w)) : a.L.at(0, 0);
+    double z[D];
+    for (int k = 0; k < D; ++k) z[k] = gp_feature(a, g.dims[k], o) * g.fscale[k];
+
+    // This wave's 16-row tiles of L^-1: w and 31 - w.  Tile t has nothing to multiply beyond column 16 t + 15 (lower
+    // triangular), so its work is proportional to t + 1 and every wave gets the same total.  Four waves share a SIMD: while
+    // one waits for its operands (every k-step pays an L2 round trip -- hipcc drains the loads before their use, they sit
+    // behind wave-uniform branches) the others keep the matrix pipe busy.
+    int tile[GPV_TPW];
+    for (int i = 0; i < GPV_TPW; ++i) tile[i] = (i & 1) ? 31 - wv - GPV_WAVES * (i >> 1) : wv + GPV_WAVES * (i >> 1);
+    const int col16 = lane & 15, kq = lane >> 4;
+    gpv_acc acc[GPV_TPW][4];
+    for (int rt = 0; rt < GPV_TPW; ++rt)
+        for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = gpv_acc{0.0, 0.0, 0.0, 0.0};
+
+    // one Matern value per lane: this lane's cell against training point 32 b + wv + GPV_WAVES i (wave-uniform: a scalar operand)
+    auto produce_one = [&](int b, int buf, int i) {
+        const int kk = wv + GPV_WAVES * i;
+        const int k = b * GPV_KB + kk;
+        double val = 0.0;
+        if (k < n) {
+            double r2 = 0.0;
+            for (int d = 0; d < D; ++d) {
+                const double t = g.Z[(long long)k * D + d] - z[d];
+                r2 += t * t;
+            }
+            double r, e;
+            matern_terms(3.0 * r2, r, e);
+            val = g.amp * (1.0 + r) * e;
+        }
+        Bs[buf][kk][lane] = val;
+    };
+    constexpr int NPROD = GPV_KB / GPV_WAVES;           // Matern values per lane and batch
+    // tile rt meets the k-step that starts at column k0 (wave-uniform)
+    auto meets = [&](int rt, int k0) { return k0 <= 16 * tile[rt] + 15 && 16 * tile[rt] < n && k0 < n; };
+    const unsigned int lane_off = (unsigned int)col16 + (unsigned int)kq * (unsigned int)n;
+    const int nbatch = (n + GPV_KB - 1) / GPV_KB;
+    for (int i = 0; i < NPROD; ++i) produce_one(0, 0, i);
+    __syncthreads();
+    for (int b = 0; b < nbatch; ++b) {
+        const bool more = b + 1 < nbatch;
+#pragma unroll
+        for (int ks = 0; ks < GPV_KB; ks += 4) {
+            const int k0 = b * GPV_KB + ks;
+            const bool kok = k0 + kq < n;
+            double bv[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) bv[ct] = Bs[b & 1][ks + kq][ct * 16 + col16];
+#pragma unroll
+            for (int rt = 0; rt < GPV_TPW; ++rt) {
+                if (!meets(rt, k0)) continue;           // wave-uniform
+                // A operand from L2: wave-uniform base (tile row, column k0) + one 32-bit lane offset (row in the tile, column
+                // in the k-step)
+                const double* base = Linv + (16 * tile[rt] + (long long)k0 * n);
+                const double av = (kok && 16 * tile[rt] + col16 < n) ? base[lane_off] : 0.0;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[ct], acc[rt][ct], 0, 0, 0);
+            }
+            // the next batch's Matern values, spread over the k-steps
+            if (more && ks % (GPV_KB / NPROD) == 0) produce_one(b + 1, (b + 1) & 1, ks / (GPV_KB / NPROD));
+        }
+        __syncthreads();
+    }
+    // |V[:, j]|^2: this wave's rows of column j = ct * 16 + (lane & 15)
+    for (int ct = 0; ct < 4; ++ct) {
+        double s = 0.0;
+        for (int rt = 0; rt < GPV_TPW; ++rt)
+            for (int r = 0; r < 4; ++r) s = fma(acc[rt][ct][r], acc[rt][ct][r], s);
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (lane < 16) part[wv][ct * 16 + lane] = s;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        double s = 0.0;
+        for (int i = 0; i < GPV_WAVES; ++i) s += part[i][lane];
+        const double out = (g.amp - s) * yscale2;
+        double best = -__builtin_inf();
+        if (cell_ok) {
+            var_plane[o] = out;
+            best = out;
+        }
+        for (int d = 32; d >= 1; d >>= 1) best = nanmax(best, __shfl_down(best, d));
+        if (lane == 0) blockmax[blockIdx.x] = best;
+    }
+}
+
 // In-library Cholesky factorisation K = L L^T (lower, in place, column-major) for the few-hundred-point
 // training sets of the surrogates: one 1024-thread workgroup, right-looking, the matrix stays in L2
 // (512^2 doubles = 2 MB).  *info = 0, or j+1 if the leading minor of order j+1 is not positive definite

@@ -180,6 +180,29 @@ def test_sound_speed_pass_serves_the_next_steps_first_pressure_evaluation(hiplib
     assert _pass_counts(prob)[1] == ra + 1                  # ... and reuse resumes with the step after
 
 
+@pytest.mark.parametrize('ntrain', [48, 200, 512])
+def test_fused_variance_kernel_matches_the_tiled_path(hiplib, monkeypatch, ntrain):
+    """k_gp_var_fused (Matern values through LDS, L^-1 Ks on the f64 matrix cores, column norms in registers) against the
+    tiled path (Ks tile in HBM, rocBLAS dgemm, norm kernel): same variance field to rounding -- both sum 48..512 squares
+    per cell in different orders -- for all three surrogates (d = 2 and d = 3), row counts that fill 2, 7 and all 16 of the
+    32-row blocks, and a cell count that is no multiple of the 64 cells of a workgroup."""
+    prob, _ = build(n=ntrain)
+    for name in ('zz', 'xz', 'yz'):
+        m = prob._gp_models[name]
+        monkeypatch.setenv('GPF_GP_VARIANCE', 'tiles')
+        m.compute_variance(on_open_step=False)
+        tiled, tiled_max = m.variance.copy(), m.maximum_variance
+        monkeypatch.delenv('GPF_GP_VARIANCE')
+        m.compute_variance(on_open_step=False)
+        fused, fused_max = m.variance.copy(), m.maximum_variance
+        scale = np.abs(tiled).max()
+        assert np.isfinite(fused).all() and scale > 0
+        # var = A - |v|^2 with |v|^2 <= A: the rounding of the sum is relative to A, not to the (possibly tiny) difference
+        prior = m.kernel_variance * float(m.Yscale)**2
+        assert np.abs(fused - tiled).max() <= 1e-11 * max(prior, scale), name
+        np.testing.assert_allclose(fused_max, tiled_max, rtol=1e-9)
+
+
 def test_predict_repredict_self_consistency(hiplib):
     """tests/test_inference.py:88-111 of the reference: a fresh prediction equals the cached re-prediction."""
     prob, _ = build()

@@ -23,3 +23,21 @@ def test_no_compiler_instruction_touches_a_row_buffer_in_flight():
     for l in lines:
         if 'ELb0ELb0E' in l:
             assert 'compiler-visible memory accesses' not in l, l
+
+
+def test_hot_kernels_of_the_shipped_build_do_not_spill():
+    """`python -m gapflow_amd.build` keeps hipcc's resource report: the fused variance kernel (16 waves per workgroup: 128
+    registers per wave is all there is) and the benchmarked step kernels must not use scratch memory -- the one time the
+    variance kernel did, it ran 3.5x slower."""
+    import re
+    path = os.path.join(ROOT, 'gapflow_amd', 'lib', 'resource_usage.txt')
+    if not os.path.exists(path):
+        pytest.skip('no resource report (library not built here)')
+    text = open(path).read()
+    seen = 0
+    for block in re.split(r'remark: Function Name: ', text)[1:]:
+        name = block.split()[0]
+        if 'k_gp_var_fused' in name or re.search(r'k_step2ILi0ELb0ELb0E', name):
+            seen += 1
+            assert int(re.search(r'ScratchSize \[bytes/lane\]: (\d+)', block).group(1)) == 0, name
+    assert seen >= 12

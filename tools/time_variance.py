@@ -24,5 +24,5 @@ with contextlib.redirect_stdout(sys.stderr):
         zz.compute_variance(on_open_step=False)
         ts.append(time.perf_counter() - t0)
     var = zz.variance
-print(f"variance pass {n}x{n} x {nt} points: {min(ts) * 1e3:.2f} ms (max var {zz.maximum_variance:.17e}, checksum {float(var.sum()):.17e})"
+print(f"[{os.path.basename(os.environ.get('GPF_LIB_PATH', 'default'))}] variance pass {n}x{n} x {nt} points: {min(ts) * 1e3:.2f} ms (max var {zz.maximum_variance:.17e}, checksum {float(var.sum()):.17e})"
       , flush=True)
