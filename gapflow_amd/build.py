@@ -21,11 +21,27 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno
 LIBS = ['-ldl']     # rocSOLVER / rocBLAS are dlopen'ed by the GP entry points (csrc/gp_kernels.hip)
 
 
-def is_stale():
-    if not os.path.exists(LIB):
+STRICT_LIB = os.path.join(LIBDIR, 'variants', 'strict.so')
+STRICT_FLAGS = ['-DGPF_STRICT_ATOMICS', '-DGPF_ONLY_EOS_DH']
+
+
+def is_stale(lib=None):
+    lib = lib or LIB
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.exists(os.path.join(CSRC, d)) and os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build_strict_variant(force=False, verbose=False):
+    """The memory-model cross-check build (aux_kernels.hip: release / acquire orders on the in-launch hand-offs instead of
+    the write-through + drained-counter form), Dowson-Higginson kernels only: half a minute of compile time.
+    tests/test_gpu_extras.py compares its fields with the default library's bit for bit."""
+    if not force and not is_stale(STRICT_LIB):
+        if verbose:
+            print('up to date, reused', STRICT_LIB)
+        return STRICT_LIB
+    return build_library(out=STRICT_LIB, extra_flags=STRICT_FLAGS, verbose=verbose)
 
 
 def build_library(force=False, verbose=False, out=None, extra_flags=()):

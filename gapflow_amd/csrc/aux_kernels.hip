@@ -250,8 +250,8 @@ struct FinishArgs {
 // gfx950: (1) a relaxed agent-scope atomic store is a write-through `global_store ... sc1` whose completion `vmcnt` counts;
 // (2) atomic adds of one lane to the same L2 are performed in issue order once earlier stores have drained; (3) a relaxed
 // agent-scope atomic load (`sc1`) is served from L2, past the CU's L1.  -DGPF_STRICT_ATOMICS builds the same kernels with
-// release / acquire orders on the arrival add and on the record loads (python -m gapflow_amd.build --variant strict
-// -DGPF_STRICT_ATOMICS; tests/test_gpu_extras.py runs the goldens on it when present): results must be identical.
+// release / acquire orders on the arrival add and on the record loads (gapflow_amd/build.py: build_strict_variant, built by
+// __graft_entry__.build(); tests/test_gpu_extras.py runs goldens on both builds): results must be identical.
 #ifdef GPF_STRICT_ATOMICS
 #define GPF_ORDER_ARRIVE __ATOMIC_ACQ_REL
 #define GPF_ORDER_LOAD __ATOMIC_ACQUIRE

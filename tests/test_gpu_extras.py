@@ -162,10 +162,10 @@ np.savez(sys.argv[1], q=p.q, dt=p.dt, ekin=p.kinetic_energy, residual=p.residual
 
 def test_strict_atomics_build_gives_identical_results(hiplib, tmp_path):
     """the in-launch hand-offs (per-block records -> last block) are ordered by write-through stores, a drained
-    arrival add and sc1 loads, not by the HIP memory model.  `python -m gapflow_amd.build --variant strict
-    -DGPF_STRICT_ATOMICS` builds the same kernels with release / acquire orders; both libraries must produce the same
-    fields, bit for bit, on a fused run (k_step2's in-kernel commit) -- run in two child processes because the library
-    path is read at import.  Skipped when the variant has not been built."""
+    arrival add and sc1 loads, not by the HIP memory model.  `__graft_entry__.build()` (gapflow_amd.build.build_strict_variant)
+    also builds the same kernels with release / acquire orders (-DGPF_STRICT_ATOMICS; Dowson-Higginson instantiations only, which
+    is what these fixtures use); both libraries must produce the same fields, bit for bit, on a fused run (k_step2's in-kernel
+    commit) -- run in two child processes because the library path is read at import."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
