@@ -196,6 +196,7 @@ def run_single(args):
             "kernel_ms": k2, "roofline": r2, "roofline_achieved_GBps": r2["achieved"], "roofline_frac": r2["frac"]}}
         if not args.no_gp:
             out["variants"]["gp_2048x2048_512pts"] = gp_variant(max(2, min(args.steps, 10)))
+            out["variants"]["gp_slab_1024x8192_rank3of8_512pts"] = gp_slab_variant(max(2, min(args.steps, 6)))
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline()
     return out
@@ -276,6 +277,50 @@ def gp_variant(steps, n=2048, ntrain=512):
                                        "algorithmic_flops_per_pass": flops_var,
                                        "note": "algorithmic flops = cells * N^2 (the triangular product); on gfx950 fp64 VALU work "
                                                "shares the f64 MFMA units, so the Matern evaluations are not hidden"}},
+    }
+
+
+GP_SLAB_YAML = """
+options: {{silent: True, write_freq: 1000000}}
+grid: {{Nx: {n}, Ny: {n}, dx: 1.e-5, dy: 1.e-5}}
+geometry: {{type: journal, CR: 1.e-2, eps: 0.7, U: 0.1, V: 0.}}
+numerics: {{CFL: 0.5, adaptive: 1, tol: 1.e-12, max_it: 100000}}
+properties: {{EOS: DH, shear: 0.0794, bulk: 0., rho0: 877.7007, P0: 101325., C1: 3.5e10, C2: 1.23}}
+gp:
+    press: {{atol: 1., rtol: 0.1, obs_stddev: 100., active_learning: False}}
+    shear: {{atol: 1., rtol: 0.1, obs_stddev: 1., active_learning: False}}
+db: {{init_size: {nt}, init_method: lhc, init_width: 0.01, init_seed: 123}}
+"""
+
+
+def gp_slab_variant(steps, n=8192, ntrain=512, world=8, rank=3):
+    """BASELINE.json configs[4] as far as ONE GPU can run it: rank 3's slab (1024 x 8192 cells, neighbours on both sides) of
+    the 8192^2 journal bearing with the three surrogates, stage-wise step, three exchanges per step looped back inside the
+    process (gapflow_amd.slab.LoopbackGroup: the rank's own rows stand in for its neighbours', so the kernels, message sizes
+    and launch sequence are the real ones and the collectives cost a device copy).  Timing only."""
+    from gapflow_amd.io import read_yaml_input
+    from gapflow_amd.slab import SlabProblem, LoopbackGroup
+    import io
+    with contextlib.redirect_stdout(sys.stderr):
+        d = read_yaml_input(io.StringIO(GP_SLAB_YAML.format(n=n, nt=ntrain)))
+        prob = SlabProblem(d, device=0, dist=LoopbackGroup(rank, world))
+        for m in prob._gp_models.values():
+            m.optimise = False
+        prob.pre_run()
+        prob.advance(1)
+        st0 = prob.state()
+        t0 = time.perf_counter()
+        prob.advance(steps)
+        st = prob.state()                                    # reads the state: drains the stream
+        t_step = (time.perf_counter() - t0) / steps
+        assert st.invalid == 0 and st.step == st0.step + steps, "GP slab steps were skipped or went invalid"
+        rows = prob.layout.nx
+        del prob
+    return {
+        "workload": f"rank {rank} of {world}: {rows} x {n} slab of the 2D journal bearing {n}x{n}, GP closures, {ntrain} training "
+                    "points (BASELINE.json configs[4]); neighbour exchange looped back inside one process",
+        "value": rows * n / t_step / 1e6, "unit": "Mcell-updates/s (this rank's cells)", "ms_per_step": t_step * 1e3, "steps": steps,
+        "whole_job_if_all_ranks_alike_Mcell_per_s": world * rows * n / t_step / 1e6,
     }
 
 

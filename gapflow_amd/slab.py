@@ -80,6 +80,38 @@ class SlabLayout:
         return g
 
 
+class LoopbackGroup:
+    """One process standing in for rank `rank` of `world` (rehearsal and timing on a one-GPU box): every peer's contribution
+    to a collective is this rank's own.  For a domain that repeats with the slab's period that is exactly what the real
+    neighbours would send (tests/test_gpu_gp_large.py); for any other domain it exercises the rank's kernels, message
+    sizes and launch sequence, not the physics across the slab boundary."""
+
+    class ReduceOp:
+        SUM, MAX, MIN = 'sum', 'max', 'min'
+
+    def __init__(self, rank, world):
+        self._rank, self._world = rank, world
+
+    def get_rank(self):
+        return self._rank
+
+    def get_world_size(self):
+        return self._world
+
+    def all_gather_into_tensor(self, out, inp):
+        out.view(self._world, -1).copy_(inp.view(1, -1).expand(self._world, -1))
+
+    def all_reduce(self, t, op=None):
+        if op == self.ReduceOp.SUM:
+            t.mul_(self._world)
+
+    def broadcast_object_list(self, box, src=0):
+        pass
+
+    def barrier(self):
+        pass
+
+
 class SlabDriver:
     """Runs the split step of an engine: step_local -> ONE all-gather -> commit.
 

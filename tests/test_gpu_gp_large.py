@@ -202,34 +202,7 @@ def test_cfg3_two_full_steps_on_a_crop_match_oracle(hiplib):
     assert prob.step == ref.step == 2
 
 
-class LoopbackGroup:
-    """One process standing in for rank `rank` of `world`: every peer's contribution is this rank's own.  For a domain
-    that repeats with the slab's period that is exactly what the real neighbours would send."""
-
-    class ReduceOp:
-        SUM, MAX, MIN = 'sum', 'max', 'min'
-
-    def __init__(self, rank, world):
-        self._rank, self._world = rank, world
-
-    def get_rank(self):
-        return self._rank
-
-    def get_world_size(self):
-        return self._world
-
-    def all_gather_into_tensor(self, out, inp):
-        out.view(self._world, -1).copy_(inp.view(1, -1).expand(self._world, -1))
-
-    def all_reduce(self, t, op=None):
-        if op == self.ReduceOp.SUM:
-            t.mul_(self._world)
-
-    def broadcast_object_list(self, box, src=0):
-        pass
-
-    def barrier(self):
-        pass
+from gapflow_amd.slab import LoopbackGroup      # one process standing in for one rank of eight
 
 
 @pytest.mark.parametrize('rank', [0, 3])
