@@ -40,45 +40,49 @@ def parabolic_slider(xx, grid, geo):
 
 
 def cdc(xx, grid, geo):
-    # topography.py:107-130 (converging - flat - diverging)
-    Lx, h0, h1, b = grid['Lx'], geo['hmin'], geo['hmax'], geo['b']
-    slope = (h1 - h0) / (Lx / 2 - 2 * b)
-    conv = (xx >= b) & (xx < Lx / 2 - b)
-    center = (xx >= Lx / 2 - b) & (xx < Lx / 2 + b)
-    div = (xx >= Lx / 2 + b) & (xx < Lx - b)
-    h = np.full_like(xx, h1)
-    h[conv] = h1 - slope * (xx[conv] - b)
-    h[center] = h0
-    h[div] = h0 + slope * (xx[div] - (Lx / 2 + b))
-    dh_dx = np.zeros_like(h)
-    dh_dx[conv] = -slope
-    dh_dx[div] = slope
-    return h, dh_dx, np.zeros_like(h)
+    """Converging - flat - diverging channel (topography.py:107-130): piecewise linear in x, flat lands of width b at both
+    ends and of width 2 b in the middle."""
+    half, land = grid['Lx'] / 2, geo['b']
+    low, high = geo['hmin'], geo['hmax']
+    slope = (high - low) / (half - 2 * land)
+    zones = [(xx >= land) & (xx < half - land),             # converging
+             (xx >= half - land) & (xx < half + land),      # flat centre
+             (xx >= half + land) & (xx < grid['Lx'] - land)]  # diverging
+    h = np.select(zones, [high - slope * (xx - land), low, low + slope * (xx - (half + land))], default=high)
+    return h, np.select(zones, [-slope, 0., slope], default=0.), np.zeros_like(xx)
+
+
+def _asperity_heights(geo):
+    """Minimum gap under each of the num^2 asperities (topography.py:141-146): hmin for a single one, otherwise draws from
+    an unseeded normal distribution around the mid-height, exactly as the reference does."""
+    low, high, n = geo['hmin'], geo['hmax'], geo['num']
+    if n == 1:
+        return np.array([low])
+    return np.random.normal(loc=low + (high - low) / 2., scale=(high - low) / 2. / 2.57, size=n**2)
+
+
+def _asperity_field(xx, yy, grid, geo, heights, centre):
+    """Cosine bumps on an n x n checkerboard (topography.py:148-170).  `centre(k, cells)` returns the centre of bump k, whose
+    cells are selected by the boolean array `cells`; bump k sits in checkerboard column k // n, row k % n."""
+    n, high = geo['num'], geo['hmax']
+    wx, wy = np.pi / (grid['Lx'] / n), np.pi / (grid['Ly'] / n)
+    col, row = (xx // (grid['Lx'] / n)).astype(int), (yy // (grid['Ly'] / n)).astype(int)
+    h, gx, gy = np.full_like(xx, high), np.zeros_like(xx), np.zeros_like(xx)
+    for k, low in enumerate(heights):
+        cells = (col == k // n) & (row == k % n)
+        if not cells.any():
+            continue
+        cx, cy = centre(k, cells)
+        depth, u, v = high - low, wx * (xx[cells] - cx), wy * (yy[cells] - cy)
+        h[cells] -= depth * (np.cos(u) * np.cos(v))
+        gx[cells] += wx * depth * (np.sin(u) * np.cos(v))
+        gy[cells] += wy * depth * (np.cos(u) * np.sin(v))
+    return h, gx, gy
 
 
 def asperity(xx, yy, grid, geo):
-    # topography.py:133-170; for num > 1 the minimum heights are drawn from an unseeded
-    # normal distribution, exactly as in the reference (topography.py:146)
-    h0, h1, num = geo['hmin'], geo['hmax'], geo['num']
-    Lx, Ly = grid['Lx'], grid['Ly']
-    if num == 1:
-        hmins = np.array([h0])
-    else:
-        std = (h1 - h0) / 2. / 2.57
-        hmins = np.random.normal(loc=h0 + (h1 - h0) / 2., scale=std, size=num**2)
-    xid = (xx // (Lx / num)).astype(int)
-    yid = (yy // (Ly / num)).astype(int)
-    bx, by = np.pi / (Lx / num), np.pi / (Ly / num)
-    h = np.full_like(xx, h1)
-    dh_dx = np.zeros_like(h)
-    dh_dy = np.zeros_like(h)
-    for k, hm in enumerate(hmins):
-        m = (xid == k // num) & (yid == k % num)
-        cx, cy = np.mean(xx[m]), np.mean(yy[m])
-        h[m] -= (h1 - hm) * (np.cos(bx * (xx[m] - cx)) * np.cos(by * (yy[m] - cy)))
-        dh_dx[m] += bx * (h1 - hm) * (np.sin(bx * (xx[m] - cx)) * np.cos(by * (yy[m] - cy)))
-        dh_dy[m] += by * (h1 - hm) * (np.cos(bx * (xx[m] - cx)) * np.sin(by * (yy[m] - cy)))
-    return h, dh_dx, dh_dy
+    # a bump's centre is the mean of the cell centres it covers (topography.py:158-159)
+    return _asperity_field(xx, yy, grid, geo, _asperity_heights(geo), lambda k, cells: (np.mean(xx[cells]), np.mean(yy[cells])))
 
 
 _PROFILES_1D = {'journal': journal_bearing, 'inclined': inclined_slider, 'parabolic': parabolic_slider, 'cdc': cdc}
@@ -100,23 +104,15 @@ def topography_rows(grid, geo, rows, hmins=None):
     if geo['type'] in _PROFILES_1D:
         h, dh_dx, dh_dy = _PROFILES_1D[geo['type']](xx, grid, geo)
     elif geo['type'] == 'asperity':
-        h0, h1, num = geo['hmin'], geo['hmax'], geo['num']
+        n = geo['num']
         if hmins is None:
-            if num != 1:
+            if n != 1:
                 raise ValueError("topography_rows: pass the shared minimum heights of the num^2 asperities")
-            hmins = np.array([h0])
-        xid_all, yid_all = (x_all // (Lx / num)).astype(int), (y // (Ly / num)).astype(int)
-        xid, yid = (xx // (Lx / num)).astype(int), (yy // (Ly / num)).astype(int)
-        bx, by = np.pi / (Lx / num), np.pi / (Ly / num)
-        h, dh_dx, dh_dy = np.full_like(xx, h1), np.zeros_like(xx), np.zeros_like(xx)
-        for k, hm in enumerate(hmins):
-            m = (xid == k // num) & (yid == k % num)
-            if not m.any():
-                continue
-            cx, cy = np.mean(x_all[xid_all == k // num]), np.mean(y[yid_all == k % num])
-            h[m] -= (h1 - hm) * (np.cos(bx * (xx[m] - cx)) * np.cos(by * (yy[m] - cy)))
-            dh_dx[m] += bx * (h1 - hm) * (np.sin(bx * (xx[m] - cx)) * np.cos(by * (yy[m] - cy)))
-            dh_dy[m] += by * (h1 - hm) * (np.cos(bx * (xx[m] - cx)) * np.sin(by * (yy[m] - cy)))
+            hmins = np.array([geo['hmin']])
+        # the centre of a bump from ALL rows / columns it covers, not only from the requested rows
+        col_all, row_all = (x_all // (Lx / n)).astype(int), (y // (Ly / n)).astype(int)
+        h, dh_dx, dh_dy = _asperity_field(xx, yy, grid, geo, hmins,
+                                          lambda k, cells: (np.mean(x_all[col_all == k // n]), np.mean(y[row_all == k % n])))
     else:
         raise IOError("Specify a valid geometry type")
     return np.stack([h, dh_dx, dh_dy])
