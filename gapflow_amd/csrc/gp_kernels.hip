@@ -248,7 +248,7 @@ __global__ __launch_bounds__(1024) void k_gp_var_tile(const double* V, int n, in
 //     hold different rows of the same column (layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 reg), then
 //     over the waves in a fixed order through LDS (deterministic).
 // Lane maps of the operands: A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15], one f64 each.
-// Measured (2048^2 cells x 512 points): 26.5 ms against 39.5 ms for the tiled path.  571 M MFMAs at 64 cycles each are
+// Measured (2048^2 cells x 512 points): 24.9 ms against 39.5 ms for the tiled path.  571 M MFMAs at 64 cycles each are
 // 14.9 ms of matrix-pipe time (SQ_VALU_MFMA_BUSY_CYCLES); the rest cannot hide behind them: on this chip the f64 matrix
 // instruction and the f64 vector ALU are the same units -- every fp64 VALU instruction between two MFMAs lengthens the pair
 // by its own 4+ cycles (tools/mfma_f64_probe.hip: 78 TFLOP/s with nothing in between, 55 with six FMAs, 43 with twelve) --
@@ -259,12 +259,20 @@ __global__ __launch_bounds__(1024) void k_gp_var_tile(const double* V, int n, in
 constexpr int GPV_CELLS = 64, GPV_KB = 32, GPV_MAX_N = 512;
 constexpr int GPV_WAVES = 16;                       // waves per workgroup
 constexpr int GPV_TPW = 32 / GPV_WAVES;             // 16-row tiles of L^-1 per wave
+#ifndef GPV_KU
+#define GPV_KU 2                                    // k-steps (of 4 columns) whose A operands are requested together: 1, 2 or 4
+                                                    // (27.0 / 24.9 / 24.4 ms; with 4 the d = 3, 4 instantiations spill)
+#endif
 typedef double gpv_acc __attribute__((ext_vector_type(4)));
 
 template <int D>
 __global__ __launch_bounds__(64 * GPV_WAVES) void k_gp_var_fused(const GpModelDev g, const double* __restrict__ Linv, const GpFieldArgs a,
                                                                  double yscale2, double* __restrict__ var_plane, double* __restrict__ blockmax) {
-    __shared__ double Bs[2][GPV_KB][GPV_CELLS];
+    // B tile of a batch, laid out the way the MFMA reads it: the 64 lanes of one read -- (k mod 4, cell mod 16) for a fixed
+    // k-step and 16-cell tile -- are 64 consecutive doubles.  (Row-major [k][cell] put the four k rows of a read 512 bytes
+    // apart, on the same banks: four-way conflicts on every read made the LDS the co-critical resource, 10 of 26 ms.)
+    __shared__ double Bs[2][GPV_KB * GPV_CELLS];
+    auto bs_index = [](int kk, int cell) { return (((kk >> 2) * 4 + (cell >> 4)) * 4 + (kk & 3)) * 16 + (cell & 15); };
     __shared__ double part[GPV_WAVES][GPV_CELLS];
     const int n = g.n;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -291,6 +299,9 @@ __global__ __launch_bounds__(64 * GPV_WAVES) void k_gp_var_fused(const GpModelDe
         const int kk = wv + GPV_WAVES * i;
         const int k = b * GPV_KB + kk;
         double val = 0.0;
+#ifdef GPV_EXP_NOPRODUCE    // (timing experiment: wrong results)
+        val = z[0] + k;
+#else
         if (k < n) {
             double r2 = 0.0;
             for (int d = 0; d < D; ++d) {
@@ -301,7 +312,8 @@ __global__ __launch_bounds__(64 * GPV_WAVES) void k_gp_var_fused(const GpModelDe
             matern_terms(3.0 * r2, r, e);
             val = g.amp * (1.0 + r) * e;
         }
-        Bs[buf][kk][lane] = val;
+#endif
+        Bs[buf][bs_index(kk, lane)] = val;
     };
     constexpr int NPROD = GPV_KB / GPV_WAVES;           // Matern values per lane and batch
     // tile rt meets the k-step that starts at column k0 (wave-uniform)
@@ -312,26 +324,43 @@ __global__ __launch_bounds__(64 * GPV_WAVES) void k_gp_var_fused(const GpModelDe
     __syncthreads();
     for (int b = 0; b < nbatch; ++b) {
         const bool more = b + 1 < nbatch;
+        // GPV_KU k-steps at a time: their A operands are requested together, then their MFMAs run back to back.  (hipcc drains
+        // the loads before the first use -- they sit behind wave-uniform branches -- so every group pays one L2 round trip; in
+        // the late batches only a few waves of a SIMD still have tiles to multiply and nothing else hides it.)
 #pragma unroll
-        for (int ks = 0; ks < GPV_KB; ks += 4) {
+        for (int ks = 0; ks < GPV_KB; ks += 4 * GPV_KU) {
             const int k0 = b * GPV_KB + ks;
-            const bool kok = k0 + kq < n;
-            double bv[4];
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) bv[ct] = Bs[b & 1][ks + kq][ct * 16 + col16];
+            double av[GPV_TPW][GPV_KU];
 #pragma unroll
             for (int rt = 0; rt < GPV_TPW; ++rt) {
-                if (!meets(rt, k0)) continue;           // wave-uniform
-                // A operand from L2: wave-uniform base (tile row, column k0) + one 32-bit lane offset (row in the tile, column
-                // in the k-step)
-                const double* base = Linv + (16 * tile[rt] + (long long)k0 * n);
-                const double av = (kok && 16 * tile[rt] + col16 < n) ? base[lane_off] : 0.0;
+                if (!meets(rt, k0)) continue;           // wave-uniform; the same for all k-steps of an aligned group of <= 16 columns
+                // A operand from L2: wave-uniform base (tile row, column) + one 32-bit lane offset (row in the tile, column in the k-step)
+                const bool rok = 16 * tile[rt] + col16 < n;
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[ct], acc[rt][ct], 0, 0, 0);
+                for (int u = 0; u < GPV_KU; ++u) {
+                    const double* base = Linv + (16 * tile[rt] + (long long)(k0 + 4 * u) * n);
+                    av[rt][u] = (rok && k0 + 4 * u + kq < n) ? base[lane_off] : 0.0;
+                }
             }
-            // the next batch's Matern values, spread over the k-steps
-            if (more && ks % (GPV_KB / NPROD) == 0) produce_one(b + 1, (b + 1) & 1, ks / (GPV_KB / NPROD));
+#pragma unroll
+            for (int u = 0; u < GPV_KU; ++u) {
+                double bv[4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) bv[ct] = Bs[b & 1][bs_index(ks + 4 * u + kq, ct * 16 + col16)];
+#pragma unroll
+                for (int rt = 0; rt < GPV_TPW; ++rt) {
+                    if (!meets(rt, k0)) continue;
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+#ifdef GPV_EXP_NOMFMA       // (timing experiment: wrong results)
+                        acc[rt][ct][0] += av[rt][u] * bv[ct];
+#else
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rt][u], bv[ct], acc[rt][ct], 0, 0, 0);
+#endif
+                }
+                // the next batch's Matern values, spread over the k-steps
+                if (more && (ks + 4 * u) % (GPV_KB / NPROD) == 0) produce_one(b + 1, (b + 1) & 1, (ks + 4 * u) / (GPV_KB / NPROD));
+            }
         }
         __syncthreads();
     }
