@@ -48,6 +48,14 @@ struct GpFieldArgs {
 // exp (argument <= 0: round-to-nearest reduction by ln 2, degree-13 polynomial, v_ldexp_f64) instead of the
 // library exp with its overflow/underflow selects.  Both are accurate to ~1 ulp on the range that matters;
 // every kernel below (K, Ks, mean) uses this one function so that K and Ks stay consistent.
+// Coefficients 1/12! ... 1/3! of the exponential's polynomial, read from constant memory: they arrive in SCALAR registers, and
+// a Horner step is one `v_fma_f64 dst, p, f, s[c]`.  As literals hipcc keeps them in VECTOR registers and spends two issue
+// slots per step (`v_mov_b64 tmp, c; v_fmac_f64 tmp, p, f`) plus 20 VGPRs.  (Inline asm would do the same but stops the
+// unroller, which the posterior-mean loop needs for its instruction-level parallelism: measured 5 % slower.)
+__device__ __constant__ double gp_exp_coef[10] = {2.08767569878681e-09, 2.505210838544172e-08, 2.755731922398589e-07, 2.7557319223985893e-06,
+                                                  2.48015873015873e-05, 1.984126984126984e-04, 1.388888888888889e-03, 8.333333333333333e-03,
+                                                  4.1666666666666664e-02, 1.6666666666666666e-01};
+
 __device__ __forceinline__ void matern_terms(double t, double& s, double& e) {
     const double tt = fmax(t, 1e-300);                      // t = 0 -> s = 1e-150, k = A exactly
     const double y = __builtin_amdgcn_rsq(tt);              // ~24-bit seed
@@ -61,16 +69,15 @@ __device__ __forceinline__ void matern_terms(double t, double& s, double& e) {
     double f = fma(n, -0.69314718036912382, x);             // ln 2 = hi + lo, hi has 21 trailing zero bits
     f = fma(n, -1.9082149292705877e-10, f);
     double p = 1.6059043836821613e-10;                      // 1/13!
-    p = fma(p, f, 2.08767569878681e-09);                    // 1/12!
-    p = fma(p, f, 2.505210838544172e-08);                   // 1/11!
-    p = fma(p, f, 2.755731922398589e-07);                   // 1/10!
-    p = fma(p, f, 2.7557319223985893e-06);                  // 1/9!
-    p = fma(p, f, 2.48015873015873e-05);                    // 1/8!
-    p = fma(p, f, 1.984126984126984e-04);                   // 1/7!
-    p = fma(p, f, 1.388888888888889e-03);                   // 1/6!
-    p = fma(p, f, 8.333333333333333e-03);                   // 1/5!
-    p = fma(p, f, 4.1666666666666664e-02);                  // 1/4!
-    p = fma(p, f, 1.6666666666666666e-01);                  // 1/3!
+#ifdef GPF_GP_PLAIN_HORNER      // (A/B: literals)
+    p = fma(p, f, 2.08767569878681e-09); p = fma(p, f, 2.505210838544172e-08); p = fma(p, f, 2.755731922398589e-07);
+    p = fma(p, f, 2.7557319223985893e-06); p = fma(p, f, 2.48015873015873e-05); p = fma(p, f, 1.984126984126984e-04);
+    p = fma(p, f, 1.388888888888889e-03); p = fma(p, f, 8.333333333333333e-03); p = fma(p, f, 4.1666666666666664e-02);
+    p = fma(p, f, 1.6666666666666666e-01);
+#else
+#pragma unroll
+    for (int k = 0; k < 10; ++k) p = fma(p, f, gp_exp_coef[k]);      // 1/12! ... 1/3!
+#endif
     p = fma(p, f, 0.5);
     p = fma(p, f, 1.0);
     p = fma(p, f, 1.0);
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(1024) void k_gp_var_tile(const double* V, int n, in
 //     hold different rows of the same column (layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 reg), then
 //     over the waves in a fixed order through LDS (deterministic).
 // Lane maps of the operands: A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15], one f64 each.
-// Measured (2048^2 cells x 512 points): 24.9 ms against 39.5 ms for the tiled path.  571 M MFMAs at 64 cycles each are
+// Measured (2048^2 cells x 512 points): 23.5 ms against 39.5 ms for the tiled path.  571 M MFMAs at 64 cycles each are
 // 14.9 ms of matrix-pipe time (SQ_VALU_MFMA_BUSY_CYCLES); the rest cannot hide behind them: on this chip the f64 matrix
 // instruction and the f64 vector ALU are the same units -- every fp64 VALU instruction between two MFMAs lengthens the pair
 // by its own 4+ cycles (tools/mfma_f64_probe.hip: 78 TFLOP/s with nothing in between, 55 with six FMAs, 43 with twelve) --
@@ -260,9 +267,9 @@ constexpr int GPV_CELLS = 64, GPV_KB = 32, GPV_MAX_N = 512;
 constexpr int GPV_WAVES = 16;                       // waves per workgroup
 constexpr int GPV_TPW = 32 / GPV_WAVES;             // 16-row tiles of L^-1 per wave
 #ifndef GPV_KU
-#define GPV_KU 2                                    // k-steps (of 4 columns) whose A operands are requested together: 1, 2 or 4
-                                                    // (27.0 / 24.9 / 24.4 ms; with 4 the d = 3, 4 instantiations spill)
-#endif
+#define GPV_KU 4                                    // k-steps (of 4 columns) whose A operands are requested together: 1, 2 or 4
+#endif                                              // (27.0 / 24.9 / 24.4 ms before the changes below; 4 needs the 20 VGPRs that
+                                                    // the exp coefficients occupied as literals, see gp_exp_coef)
 typedef double gpv_acc __attribute__((ext_vector_type(4)));
 
 template <int D>
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(64 * GPV_WAVES) void k_gp_var_fused(const GpModelDe
     // B tile of a batch, laid out the way the MFMA reads it: the 64 lanes of one read -- (k mod 4, cell mod 16) for a fixed
     // k-step and 16-cell tile -- are 64 consecutive doubles.  (Row-major [k][cell] put the four k rows of a read 512 bytes
     // apart, on the same banks: four-way conflicts on every read made the LDS the co-critical resource, 10 of 26 ms.)
-    __shared__ double Bs[2][GPV_KB * GPV_CELLS];
+    __shared__ double Bs[4][GPV_KB * GPV_CELLS];        // two phases (double buffer) x two batches per phase
     auto bs_index = [](int kk, int cell) { return (((kk >> 2) * 4 + (cell >> 4)) * 4 + (kk & 3)) * 16 + (cell & 15); };
     __shared__ double part[GPV_WAVES][GPV_CELLS];
     const int n = g.n;
@@ -320,13 +327,20 @@ __global__ __launch_bounds__(64 * GPV_WAVES) void k_gp_var_fused(const GpModelDe
     auto meets = [&](int rt, int k0) { return k0 <= 16 * tile[rt] + 15 && 16 * tile[rt] < n && k0 < n; };
     const unsigned int lane_off = (unsigned int)col16 + (unsigned int)kq * (unsigned int)n;
     const int nbatch = (n + GPV_KB - 1) / GPV_KB;
-    for (int i = 0; i < NPROD; ++i) produce_one(0, 0, i);
+    // Batch b has 32 - 2 b tiles at work: alone, the late batches would leave most waves idle and the few busy ones exposed
+    // to the latency of their operand loads.  The order of the columns is free (a sum), so batch p is paired with batch
+    // nbatch - 1 - p in one phase: every phase then has the same amount of work, and every wave two or three tile-batches
+    // of it.  Slot 0 / 1 of the LDS buffer holds the B tile of the lower / upper batch of the phase.
+    const int nphase = (nbatch + 1) / 2;
+    auto batch_of = [&](int phase, int slot) { return slot == 0 ? phase : nbatch - 1 - phase; };
+    auto paired = [&](int phase) { return nbatch - 1 - phase != phase; };          // the middle batch of an odd count is alone
+    for (int i = 0; i < NPROD; ++i) produce_one(batch_of(0, 0), 0, i);
+    if (paired(0)) for (int i = 0; i < NPROD; ++i) produce_one(batch_of(0, 1), 1, i);
     __syncthreads();
-    for (int b = 0; b < nbatch; ++b) {
-        const bool more = b + 1 < nbatch;
-        // GPV_KU k-steps at a time: their A operands are requested together, then their MFMAs run back to back.  (hipcc drains
-        // the loads before the first use -- they sit behind wave-uniform branches -- so every group pays one L2 round trip; in
-        // the late batches only a few waves of a SIMD still have tiles to multiply and nothing else hides it.)
+    // the products of one batch: GPV_KU k-steps at a time -- their A operands are requested together, then their MFMAs run
+    // back to back (hipcc drains the loads before the first use, they sit behind wave-uniform branches: one L2 round trip
+    // per group).  `next`, `nslot`: between the k-steps, the Matern values of a batch of the next phase are produced.
+    auto consume = [&](int b, int buf, int next, int nbuf) {
 #pragma unroll
         for (int ks = 0; ks < GPV_KB; ks += 4 * GPV_KU) {
             const int k0 = b * GPV_KB + ks;
@@ -346,7 +360,7 @@ __global__ __launch_bounds__(64 * GPV_WAVES) void k_gp_var_fused(const GpModelDe
             for (int u = 0; u < GPV_KU; ++u) {
                 double bv[4];
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) bv[ct] = Bs[b & 1][bs_index(ks + 4 * u + kq, ct * 16 + col16)];
+                for (int ct = 0; ct < 4; ++ct) bv[ct] = Bs[buf][bs_index(ks + 4 * u + kq, ct * 16 + col16)];
 #pragma unroll
                 for (int rt = 0; rt < GPV_TPW; ++rt) {
                     if (!meets(rt, k0)) continue;
@@ -358,9 +372,18 @@ __global__ __launch_bounds__(64 * GPV_WAVES) void k_gp_var_fused(const GpModelDe
                         acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rt][u], bv[ct], acc[rt][ct], 0, 0, 0);
 #endif
                 }
-                // the next batch's Matern values, spread over the k-steps
-                if (more && (ks + 4 * u) % (GPV_KB / NPROD) == 0) produce_one(b + 1, (b + 1) & 1, (ks + 4 * u) / (GPV_KB / NPROD));
+                if (next >= 0 && (ks + 4 * u) % (GPV_KB / NPROD) == 0) produce_one(next, nbuf, (ks + 4 * u) / (GPV_KB / NPROD));
             }
+        }
+    };
+    for (int ph = 0; ph < nphase; ++ph) {
+        const int cur = 2 * (ph & 1), nxt = 2 * ((ph + 1) & 1);        // buffer pairs alternate between phases
+        const bool more = ph + 1 < nphase;
+        // (one copy of the batch body in the binary: two inlined copies overflow the 128 registers of a wave)
+#pragma unroll 1
+        for (int slot = 0; slot < (paired(ph) ? 2 : 1); ++slot) {
+            const bool feeds = more && (slot == 0 || paired(ph + 1));
+            consume(batch_of(ph, slot), cur + slot, feeds ? batch_of(ph + 1, slot) : -1, nxt + slot);
         }
         __syncthreads();
     }
