@@ -180,7 +180,7 @@ def test_sound_speed_pass_serves_the_next_steps_first_pressure_evaluation(hiplib
     assert _pass_counts(prob)[1] == ra + 1                  # ... and reuse resumes with the step after
 
 
-@pytest.mark.parametrize('ntrain', [48, 200, 512])
+@pytest.mark.parametrize('ntrain', [5, 48, 200, 257, 512])
 def test_fused_variance_kernel_matches_the_tiled_path(hiplib, monkeypatch, ntrain):
     """k_gp_var_fused (Matern values through LDS, L^-1 Ks on the f64 matrix cores, column norms in registers) against the
     tiled path (Ks tile in HBM, rocBLAS dgemm, norm kernel): same variance field to rounding -- both sum 48..512 squares
