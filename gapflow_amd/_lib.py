@@ -107,6 +107,9 @@ SIGNATURES = {
     'gpf_gp_clear_model': (C.c_int, [C.c_void_p, C.c_int]),
     'gpf_gp_variance': (C.c_int, [C.c_void_p, C.c_int, C.c_int, _DP]),
     'gpf_gp_pass_counts': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    'gpf_gp_nll_open': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _DP, _DP, C.c_double, C.POINTER(C.c_void_p)]),
+    'gpf_gp_nll_eval': (C.c_int, [C.c_void_p, _DP, _DP, _DP, C.POINTER(C.c_int)]),
+    'gpf_gp_nll_close': (C.c_int, [C.c_void_p]),
 }
 
 _lib = None

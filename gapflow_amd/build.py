@@ -1,6 +1,6 @@
 """Builds libgapflow_hip.so (gfx950 only) in-tree with hipcc.
 
-    python -m gapflow_amd.build [--force]
+    python -m gapflow_amd.build [--force] [--no-strict]
 
 hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels to the
 GPU box with the working tree.
@@ -74,3 +74,5 @@ if __name__ == '__main__':
         build_library(out=os.path.join(LIBDIR, 'variants', sys.argv[i + 1] + '.so'), extra_flags=sys.argv[i + 2:], verbose=True)
     else:
         build_library(force='--force' in sys.argv, verbose=True)
+        if '--no-strict' not in sys.argv:       # keep the cross-check variant in step with the sources (its ABI must match)
+            build_strict_variant(force='--force' in sys.argv, verbose=True)

@@ -411,6 +411,62 @@ __global__ __launch_bounds__(64 * GPV_WAVES) void k_gp_var_fused(const GpModelDe
     }
 }
 
+// Gradient of the negative log marginal likelihood (gp.py:307-318 through jax.grad in the reference):
+//   dL/dtheta_k = -1/2 tr(W dK/dtheta_k),  W = alpha alpha^T - m K^-1,
+//   dK/dlog_amp = Kf (the kernel matrix without the noise diagonal),
+//   dK/dlog_scale_j = 3 A exp(-r) s_j^2 d_j^2   (d_j the coordinate difference, s_j = exp(-log_scale_j)).
+// One thread per matrix entry recomputes its kernel value from the RAW inputs X and accumulates its 1 + d products; per-block
+// partial sums in a fixed order (deterministic), folded by the host.  Kinv: full symmetric n x n, column-major.
+template <int D>
+__global__ __launch_bounds__(256) void k_gp_nll_grad(const double* __restrict__ X, const double* __restrict__ alpha, const double* __restrict__ Kinv,
+                                                     int n, int m, double amp, const double* __restrict__ inv_scale, double* __restrict__ partial) {
+    __shared__ double red[4][1 + D];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    double acc[1 + D];
+    for (int k = 0; k <= D; ++k) acc[k] = 0.0;
+    if (i < n) {
+        double t[D], r2 = 0.0;
+        for (int k = 0; k < D; ++k) {
+            const double dz = (X[(long long)i * D + k] - X[(long long)j * D + k]) * inv_scale[k];
+            t[k] = dz * dz;
+            r2 += t[k];
+        }
+        double r, e;
+        matern_terms(3.0 * r2, r, e);
+        double w = -(double)m * Kinv[i + (long long)j * n];
+        for (int o = 0; o < m; ++o) w = fma(alpha[i + (long long)o * n], alpha[j + (long long)o * n], w);
+        acc[0] = w * (amp * (1.0 + r) * e);
+        const double we = w * e;
+        for (int k = 0; k < D; ++k) acc[1 + k] = we * t[k];       // t_k = s_k^2 d_k^2
+    }
+    for (int k = 0; k <= D; ++k) {
+        double v = acc[k];
+        for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_down(v, sft);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x <= D) {
+        const int k = threadIdx.x;
+        partial[((long long)blockIdx.y * gridDim.x + blockIdx.x) * (1 + D) + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    }
+}
+
+// kernel matrix from RAW inputs: K = A (1 + r) exp(-r) + sigma^2 I with r = sqrt(3 sum_k ((x_ik - x_jk) s_k)^2)
+template <int D>
+__global__ void k_gp_nll_matrix(const double* __restrict__ X, int n, double amp, const double* __restrict__ inv_scale, double sigma2,
+                                double* __restrict__ K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (i >= n) return;
+    double r2 = 0.0;
+    for (int k = 0; k < D; ++k) {
+        const double dz = (X[(long long)i * D + k] - X[(long long)j * D + k]) * inv_scale[k];
+        r2 += dz * dz;
+    }
+    double r, e;
+    matern_terms(3.0 * r2, r, e);
+    K[i + (long long)j * n] = amp * (1.0 + r) * e + (i == j ? sigma2 : 0.0);
+}
+
 // In-library Cholesky factorisation K = L L^T (lower, in place, column-major) for the few-hundred-point
 // training sets of the surrogates: one 1024-thread workgroup, right-looking, the matrix stays in L2
 // (512^2 doubles = 2 MB).  *info = 0, or j+1 if the leading minor of order j+1 is not positive definite

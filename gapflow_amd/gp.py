@@ -87,6 +87,52 @@ class NegLogLikelihood:
         return f, g
 
 
+class DeviceNegLogLikelihood:
+    """theta -> (value, gradient) evaluated by the library (gpf_gp_nll_*: kernel matrix, Cholesky, K^-1 and the gradient sums
+    on the device; the optimiser stays on the host, as the reference's jaxopt.ScipyMinimize does).  Same arithmetic as
+    NegLogLikelihood, which remains the statement of it that the tests compare with; use as a context manager."""
+
+    def __init__(self, X, Y, sigma, device=0):
+        self._lib = _lib.require_device()
+        X = _lib.f64c(np.asarray(X, float))
+        Y = _lib.f64c(np.asarray(Y, float).reshape(len(X), -1))
+        self._h = C.c_void_p()
+        _lib.check(self._lib.gpf_gp_nll_open(device, X.shape[0], X.shape[1], Y.shape[1], _lib.as_dp(X), _lib.as_dp(Y), float(sigma),
+                                             C.byref(self._h)))
+        self._nd = X.shape[1]
+        self.not_positive_definite = 0      # probes at which the device factorisation found a non-positive pivot
+
+    def __call__(self, theta):
+        theta = _lib.f64c(np.asarray(theta, float))
+        if not np.all(np.isfinite(theta)):
+            return 1e300, np.zeros_like(theta)
+        value, info = C.c_double(0.0), C.c_int(0)
+        grad = np.zeros(1 + self._nd)
+        _lib.check(self._lib.gpf_gp_nll_eval(self._h, _lib.as_dp(theta), C.byref(value), _lib.as_dp(grad), C.byref(info)))
+        if info.value > 0:
+            self.not_positive_definite += 1
+        if info.value != 0 or not np.isfinite(value.value) or not np.all(np.isfinite(grad)):
+            return 1e300, np.zeros_like(theta)         # a line-search probe far outside the sensible range: reject the step
+        return value.value, grad
+
+    def close(self):
+        if self._h:
+            self._lib.gpf_gp_nll_close(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
 def neg_log_likelihood(theta, X, Y, sigma):
     """Value and gradient w.r.t. theta = [log_amp, log_scale_1..d] (gp.py:307-318, 598-603)."""
     return NegLogLikelihood(X, Y, sigma)(theta)
@@ -381,8 +427,23 @@ class Surrogate:
         theta0 = np.concatenate([[0.0], np.log(np.std(X, axis=0))])         # stress.py:281-284, 592-595
         if optimise or self.theta is None:
             if optimise:
-                with _single_threaded_blas():
-                    res = minimize(NegLogLikelihood(X, Y, sigma), theta0, jac=True, method='BFGS')
+                # objective and gradient on the device (GPF_GP_TRAIN=host: the NumPy / LAPACK statement of the same arithmetic)
+                if os.environ.get('GPF_GP_TRAIN', 'device') == 'host':
+                    with _single_threaded_blas():
+                        res = minimize(NegLogLikelihood(X, Y, sigma), theta0, jac=True, method='BFGS')
+                else:
+                    dev = self._p._cfg.device if hasattr(self._p, '_cfg') else getattr(self._p, '_device', 0)
+                    with DeviceNegLogLikelihood(X, Y, sigma, device=dev) as nll:
+                        res = minimize(nll, theta0, jac=True, method='BFGS')
+                        rejected = nll.not_positive_definite
+                    # With a numerically singular K (observation noise ~1e-8 of the output scale) two Cholesky codes disagree on
+                    # whether a probe is still positive definite; where the device factorisation gave up on probes that LAPACK
+                    # may still factorise, the search can stop early: the host statement then continues from where it stopped.
+                    if rejected:
+                        with _single_threaded_blas():
+                            host_nll = NegLogLikelihood(X, Y, sigma)
+                            start = res.x if host_nll(res.x)[0] < 1e300 else theta0
+                            res = minimize(host_nll, start, jac=True, method='BFGS')
                 self.theta, obj = res.x, res.fun
             else:
                 self.theta, obj = theta0, neg_log_likelihood(theta0, X, Y, sigma)[0]

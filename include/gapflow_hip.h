@@ -284,6 +284,18 @@ int gpf_gp_variance(gpf_handle* h, int which, int on_open_step, double* max_var)
  * turns the reuse off. */
 int gpf_gp_pass_counts(gpf_handle* h, int64_t launched[3], int64_t* reused);
 
+/* Hyper-parameter training on the device (replaces what tinygp + jax.grad + jaxopt evaluate per optimiser step,
+ * gp.py:290-335, 576-603): -log p(Y | X, theta) and its gradient for theta = [log_amp, log_scale_1..d] of the
+ * Matern-3/2 ARD kernel with fixed observation noise sigma.  A session keeps the training set (Xn: n x d row-major,
+ * normalised inputs; Yn: n x m row-major) and its work space on the device; the optimiser (host, SciPy BFGS as
+ * the reference's jaxopt.ScipyMinimize) calls gpf_gp_nll_eval once per step: kernel matrix from the raw inputs,
+ * blocked Cholesky, alpha, log det, K^-1 = L^-T L^-1 (rocBLAS dtrsm + dgemm), and one pass over the n x n entries for the
+ * 1 + d gradient sums.  *info != 0: K is not positive definite at this theta (the optimiser rejects the step). */
+typedef struct gpf_nll gpf_nll;
+int gpf_gp_nll_open(int device, int n, int d, int m, const double* Xn, const double* Yn, double sigma, gpf_nll** out);
+int gpf_gp_nll_eval(gpf_nll* s, const double* theta, double* value, double* grad, int* info);
+int gpf_gp_nll_close(gpf_nll* s);
+
 /* Diagnostic: time of one pass of an elementwise kernel that reads `nin` and writes `nout` fp64 planes of
  * `doubles_per_plane` elements (16 bytes per lane, grid-stride): what THIS device streams for the byte count of a fused
  * step.  bench.py reports it beside the step kernel's HBM figure (no reference counterpart: the reference has no device). */

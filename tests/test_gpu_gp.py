@@ -203,6 +203,49 @@ def test_fused_variance_kernel_matches_the_tiled_path(hiplib, monkeypatch, ntrai
         np.testing.assert_allclose(fused_max, tiled_max, rtol=1e-9)
 
 
+@pytest.mark.parametrize('n,d,m', [(64, 2, 1), (200, 3, 2), (512, 3, 2)])
+def test_device_likelihood_matches_the_host_statement(hiplib, n, d, m):
+    """gpf_gp_nll_eval (kernel matrix, Cholesky, K^-1 and the gradient sums on the device) against NegLogLikelihood (NumPy +
+    LAPACK; itself compared with the oracle and with finite differences in tests/test_host_gp.py): value and gradient at
+    three thetas around the starting point of a training, and a theta at which K is not positive definite."""
+    from gapflow_amd.gp import NegLogLikelihood, DeviceNegLogLikelihood
+    rng = np.random.default_rng(n + d)
+    X = rng.uniform(-1., 1., (n, d))
+    Y = np.column_stack([np.sin(2 * X[:, 0]) * (1 + 0.3 * X[:, -1]) + 0.01 * rng.standard_normal(n) for _ in range(m)])
+    sigma = 0.02
+    host = NegLogLikelihood(X, Y, sigma)
+    theta0 = np.concatenate([[0.0], np.log(np.std(X, axis=0))])
+    with DeviceNegLogLikelihood(X, Y, sigma) as dev:
+        for shift in (0.0, 0.4, -0.7):
+            theta = theta0 + shift * np.linspace(1., -1., 1 + d)
+            fh, gh = host(theta)
+            fd, gd = dev(theta)
+            np.testing.assert_allclose(fd, fh, rtol=1e-10, atol=1e-8)
+            np.testing.assert_allclose(gd, gh, rtol=1e-7, atol=1e-7 * np.abs(gh).max())
+        bad = np.concatenate([[40.0], np.full(d, 30.0)])         # amplitude e^40, all points on top of each other: singular
+        assert dev(bad)[0] == 1e300 == host(bad)[0]
+
+
+def test_training_on_the_device_finds_the_host_optimum(hiplib, monkeypatch):
+    """Surrogate.train with the objective on the device (default) and with GPF_GP_TRAIN=host: BFGS from the same start ends
+    at the same objective value (1e-6 of it).  The hyper-parameters themselves agree only where the likelihood determines
+    them: a length scale of e^16 (an input the pressure does not depend on) is a flat direction in which BFGS stops wherever
+    rounding takes it."""
+    from gapflow_amd.gp import NegLogLikelihood
+    thetas = {}
+    for mode in ('device', 'host'):
+        monkeypatch.setenv('GPF_GP_TRAIN', mode)
+        prob, _ = build(n=96)
+        m = prob._gp_models['zz']
+        m.train(reason=0, optimise=True)
+        thetas[mode] = m.theta.copy()
+    nll = NegLogLikelihood(m.Xtrain, m.Ytrain, m.Yerr)
+    fd, fh = nll(thetas['device'])[0], nll(thetas['host'])[0]
+    assert abs(fd - fh) <= 1e-6 * abs(fh), (fd, fh, thetas)
+    well = np.exp(-thetas['host'][1:]) > 1e-3            # inverse length scales that matter
+    np.testing.assert_allclose(thetas['device'][1:][well], thetas['host'][1:][well], atol=0.05)
+
+
 def test_predict_repredict_self_consistency(hiplib):
     """tests/test_inference.py:88-111 of the reference: a fresh prediction equals the cached re-prediction."""
     prob, _ = build()
