@@ -537,6 +537,24 @@ __global__ void k_gp_logdet(const double* Lm, int n, double* out) {
     out[0] = 2.0 * s;
 }
 
+// Panel solve of the blocked Cholesky: A21 <- A21 L11^-T by forward substitution, one thread per row of the panel, the jb x jb
+// diagonal factor (jb <= 64) in LDS.  rocBLAS dtrsm solves through inverted diagonal blocks, whose error grows with cond(L11)^2;
+// on the numerically singular kernel matrices a trained surrogate produces (noise 1e-5 of the amplitude: cond(K) ~ 1/eps) that
+// made the blocked factorisation report a non-positive pivot where LAPACK and the unblocked kernel succeed.
+__global__ __launch_bounds__(256) void k_gp_panel_solve(const double* __restrict__ L11, int jb, int lda, double* A21, int rest) {
+    __shared__ double sl[64][65];
+    for (int t = threadIdx.x; t < jb * jb; t += blockDim.x) sl[t / jb][t % jb] = L11[(t / jb) + (long long)(t % jb) * lda];    // sl[j][k] = L11(j, k)
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rest) return;
+    // (the row's earlier results are read back from A21 itself -- this thread wrote them --: no private array, no scratch)
+    for (int j = 0; j < jb; ++j) {
+        double a = A21[i + (long long)j * lda];
+        for (int k = 0; k < j; ++k) a = fma(-A21[i + (long long)k * lda], sl[j][k], a);
+        A21[i + (long long)j * lda] = a / sl[j][j];
+    }
+}
+
 // zero the strict upper triangle so L can be handed out as a clean lower-triangular matrix
 // n x n identity, column-major
 __global__ void k_gp_identity(double* I, int n) {

@@ -246,6 +246,45 @@ def test_training_on_the_device_finds_the_host_optimum(hiplib, monkeypatch):
     np.testing.assert_allclose(thetas['device'][1:][well], thetas['host'][1:][well], atol=0.05)
 
 
+def test_blocked_cholesky_factorises_a_numerically_singular_trained_kernel_matrix(hiplib):
+    """What training produces on a narrow Latin-hypercube sample: amplitude e^11.7 over noise 6e-5 -- the smallest eigenvalue of
+    K computes to -2e-9, LAPACK's dpotrf still succeeds (smallest pivot ~ sigma).  The blocked device factorisation must too
+    (its panel solve is a substitution kernel for that reason: through rocBLAS dtrsm's inverted diagonal blocks it reported a
+    non-positive pivot here and the run died in gpf_gp_set_model), with the same factor to 1e-4 of sigma-sized entries."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from scipy.linalg import lapack
+    from bench import GP_YAML
+    from gapflow_amd import Problem, _lib
+    text = GP_YAML.format(n=64, nt=256).replace('obs_stddev: 100., active_learning: False', 'obs_stddev: 1.e5, active_learning: False')
+    prob = Problem.from_string(text)
+    for m in prob._gp_models.values():
+        m.optimise = False
+    prob._pre_run()
+    m = prob._gp_models['zz']
+    X, Y, s = m.Xtrain, m.Ytrain, m.Yerr
+    th = np.array([11.70824469, 2.93533174, 14.77329233])          # the optimum BFGS finds for this training set
+    amp, inv = np.exp(th[0]), np.exp(-th[1:])
+    Z = X * inv
+    r = np.sqrt(3 * ((Z[:, None, :] - Z[None, :, :])**2).sum(-1))
+    K = amp * (1 + r) * np.exp(-r) + s**2 * np.eye(len(X))
+    assert np.linalg.eigvalsh(K)[0] < 1e-6 * s**2 + 1e-8             # numerically singular
+    c, info = lapack.dpotrf(K, lower=True)
+    assert info == 0
+    L, alpha, ld = np.zeros_like(K), np.zeros((len(X), 1)), C.c_double()
+    lib = _lib.require_device()
+    rc = lib.gpf_gp_fit(0, len(X), X.shape[1], 1, _lib.as_dp(_lib.f64c(X)), _lib.as_dp(_lib.f64c(Y)), amp, _lib.as_dp(_lib.f64c(inv)), s,
+                        _lib.as_dp(L), _lib.as_dp(alpha), C.byref(ld))
+    assert rc == 0, lib.gpf_last_error().decode()
+    assert np.diag(L).min() > 0.5 * s
+    assert np.abs(L - np.tril(c)).max() <= 1e-4 * np.abs(c).max()
+    # and the model attaches: mean and variance evaluate
+    m.theta = th
+    m.attach()
+    m.compute_variance(on_open_step=False)
+    assert np.isfinite(m.maximum_variance)
+
+
 def test_predict_repredict_self_consistency(hiplib):
     """tests/test_inference.py:88-111 of the reference: a fresh prediction equals the cached re-prediction."""
     prob, _ = build()
