@@ -42,21 +42,42 @@ struct GpFieldArgs {
     double* blockmax;               // per-block max of d mean/d x_0 (WITH_GRAD) or nullptr
 };
 
-// Matern-3/2 pieces for t = 3 r^2 >= 0:  s = sqrt(t),  e = exp(-s);  k = A (1 + s) e,  dk/ds ~ s e.
-// The posterior-mean kernel runs at 98 % VALU issue (profiles/r01_c_gp), so the instruction count of this
-// function IS its speed: v_rsq_f64 + Goldschmidt instead of the range-scaled library sqrt, and a branch-free
-// exp (argument <= 0: round-to-nearest reduction by ln 2, degree-13 polynomial, v_ldexp_f64) instead of the
-// library exp with its overflow/underflow selects.  Both are accurate to ~1 ulp on the range that matters;
-// every kernel below (K, Ks, mean) uses this one function so that K and Ks stay consistent.
-// Coefficients 1/12! ... 1/3! of the exponential's polynomial, read from constant memory: they arrive in SCALAR registers, and
-// a Horner step is one `v_fma_f64 dst, p, f, s[c]`.  As literals hipcc keeps them in VECTOR registers and spends two issue
-// slots per step (`v_mov_b64 tmp, c; v_fmac_f64 tmp, p, f`) plus 20 VGPRs.  (Inline asm would do the same but stops the
-// unroller, which the posterior-mean loop needs for its instruction-level parallelism: measured 5 % slower.)
-__device__ __constant__ double gp_exp_coef[10] = {2.08767569878681e-09, 2.505210838544172e-08, 2.755731922398589e-07, 2.7557319223985893e-06,
-                                                  2.48015873015873e-05, 1.984126984126984e-04, 1.388888888888889e-03, 8.333333333333333e-03,
-                                                  4.1666666666666664e-02, 1.6666666666666666e-01};
+// 2^(j/64), j = 0..63, correctly rounded: the exponential below is exp(x) = 2^m 2^(j/64) exp(f) with |f| <= ln2 / 128, a
+// degree-5 polynomial.  Kernels copy the table into LDS once (gp_exp_table_to_lds) and index it per lane.
+__device__ __constant__ double gp_exp2_tab[64] = {
+    1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284,
+    1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199,
+    1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418,
+    1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812,
+    1.189207115002721, 1.202156731452703, 1.215247359980469, 1.22848053610687,
+    1.241857812073484, 1.255380757024691, 1.2690509571917332, 1.2828700160787783,
+    1.2968395546510096, 1.3109612115247644, 1.3252366431597413, 1.339667524053303,
+    1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112,
+    1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647,
+    1.4768261459394993, 1.4929077282912648, 1.5091644275934228, 1.5255981507445384,
+    1.5422108254079407, 1.559004400237837, 1.5759808451078865, 1.593142151342267,
+    1.6104903319492543, 1.6280274218573478, 1.645755478153965, 1.6636765803267364,
+    1.681792830507429, 1.7001063537185235, 1.718619298122478, 1.7373338352737062,
+    1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989,
+    1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656,
+    1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.978456026387951};
 
-__device__ __forceinline__ void matern_terms(double t, double& s, double& e) {
+// called by all threads of a block before the first matern_terms; `tab` is a __shared__ double[64]
+__device__ __forceinline__ void gp_exp_table_to_lds(double* tab) {
+    if (threadIdx.x < 64) tab[threadIdx.x] = gp_exp2_tab[threadIdx.x];
+    __syncthreads();
+}
+
+// Matern-3/2 pieces for t = 3 r^2 >= 0:  s = sqrt(t),  e = exp(-s);  k = A (1 + s) e,  dk/ds ~ s e.
+// These kernels are bound by the fp64 units (on gfx950 only the double-precision operations cost four cycles per wave; moves,
+// integer operations and LDS reads ride along), so the NUMBER of fp64 operations of this function is their speed:
+//   * sqrt: v_rsq_f64 + two Goldschmidt steps (8 operations) instead of the range-scaled library sqrt;
+//   * exp (argument <= 0): reduction by ln2/64 (round to nearest, hi/lo split), a 64-entry table of 2^(j/64) in LDS, a
+//     degree-5 polynomial and v_ldexp_f64 -- 12 operations instead of the 19 of a degree-13 polynomial after a reduction by ln 2
+//     (and far fewer than the library exp with its overflow / underflow selects).
+// Accurate to 1.5 ulp (exp) and 1 ulp (sqrt) on the range that matters; every kernel below (K, Ks, mean, variance, likelihood)
+// uses this one function, so K and Ks stay consistent.
+__device__ __forceinline__ void matern_terms(double t, double& s, double& e, const double* __restrict__ tab) {
     const double tt = fmax(t, 1e-300);                      // t = 0 -> s = 1e-150, k = A exactly
     const double y = __builtin_amdgcn_rsq(tt);              // ~24-bit seed
     double g = tt * y, h = 0.5 * y;
@@ -65,23 +86,17 @@ __device__ __forceinline__ void matern_terms(double t, double& s, double& e) {
     r = fma(-h, g, 0.5);
     s = fma(g, r, g);
     const double x = -fmin(s, 800.0);                       // exp(-800) = 0 in fp64 anyway
-    const double n = __builtin_rint(x * 1.4426950408889634);
-    double f = fma(n, -0.69314718036912382, x);             // ln 2 = hi + lo, hi has 21 trailing zero bits
-    f = fma(n, -1.9082149292705877e-10, f);
-    double p = 1.6059043836821613e-10;                      // 1/13!
-#ifdef GPF_GP_PLAIN_HORNER      // (A/B: literals)
-    p = fma(p, f, 2.08767569878681e-09); p = fma(p, f, 2.505210838544172e-08); p = fma(p, f, 2.755731922398589e-07);
-    p = fma(p, f, 2.7557319223985893e-06); p = fma(p, f, 2.48015873015873e-05); p = fma(p, f, 1.984126984126984e-04);
-    p = fma(p, f, 1.388888888888889e-03); p = fma(p, f, 8.333333333333333e-03); p = fma(p, f, 4.1666666666666664e-02);
-    p = fma(p, f, 1.6666666666666666e-01);
-#else
-#pragma unroll
-    for (int k = 0; k < 10; ++k) p = fma(p, f, gp_exp_coef[k]);      // 1/12! ... 1/3!
-#endif
+    const double n = __builtin_rint(x * 92.332482616893657);            // 64 / ln 2
+    double f = fma(n, -0.010830424693267560, x);            // ln2 / 64 = hi + lo; hi = (ln2 hi) / 64 keeps its 21 trailing zero bits
+    f = fma(n, -2.9815858269852933e-12, f);
+    double p = 8.3333333333333332e-03;                      // 1/5!
+    p = fma(p, f, 4.1666666666666664e-02);                  // 1/4!
+    p = fma(p, f, 1.6666666666666666e-01);                  // 1/3!
     p = fma(p, f, 0.5);
     p = fma(p, f, 1.0);
     p = fma(p, f, 1.0);
-    e = ldexp(p, (int)n);
+    const int ni = (int)n;
+    e = ldexp(tab[ni & 63] * p, ni >> 6);                   // arithmetic shift: floor(n / 64) for the negative n
 }
 
 __device__ __forceinline__ double gp_feature(const GpFieldArgs& a, int f, long long o) {
@@ -92,6 +107,8 @@ __device__ __forceinline__ double gp_feature(const GpFieldArgs& a, int f, long l
 
 // K (column-major n x n) = k(Z, Z) + sigma^2 I, with Z already in kernel coordinates
 __global__ void k_gp_matrix(const double* Z, int n, int d, double amp, double sigma2, double* K) {
+    __shared__ double exptab[64];
+    gp_exp_table_to_lds(exptab);
     const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
     if (i >= n) return;
     double r2 = 0.0;
@@ -100,7 +117,7 @@ __global__ void k_gp_matrix(const double* Z, int n, int d, double amp, double si
         r2 += t * t;
     }
     double r, e;                                      // r = sqrt3 * |dz|
-    matern_terms(3.0 * r2, r, e);
+    matern_terms(3.0 * r2, r, e, exptab);
     K[i + (long long)j * n] = amp * (1.0 + r) * e + (i == j ? sigma2 : 0.0);
 }
 
@@ -110,6 +127,8 @@ __global__ __launch_bounds__(256) void k_gp_mean(const GpModelDev g, const GpFie
     __shared__ double sZ[GP_CHUNK * D];
     __shared__ double sA[GP_CHUNK * M];
     __shared__ double sred[4];
+    __shared__ double exptab[64];
+    gp_exp_table_to_lds(exptab);
     const long long w = a.L.Ny + 2, ncell = (long long)(a.L.Nx + 2) * w;
     const long long cell = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const bool active = cell < ncell;
@@ -137,7 +156,7 @@ __global__ __launch_bounds__(256) void k_gp_mean(const GpModelDev g, const GpFie
                 r2 += t * t;
             }
             double r, e;
-            matern_terms(3.0 * r2, r, e);
+            matern_terms(3.0 * r2, r, e, exptab);
             const double kv = fma(r, e, e);
             for (int k = 0; k < M; ++k) acc[k] += sA[k * cnt + i] * kv;
             if (WITH_GRAD) gacc += sA[i] * d0 * e;
@@ -177,6 +196,8 @@ __global__ void k_gp_maxreduce(const double* in, int n, double scale, double* ou
 template <int D>
 __global__ __launch_bounds__(256) void k_gp_ks_tile(const GpModelDev g, const GpFieldArgs a, long long cell0, int ncols,
                                                     double* Ks) {
+    __shared__ double exptab[64];
+    gp_exp_table_to_lds(exptab);
     const long long w = a.L.Ny + 2;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;      // training point
     const int j = blockIdx.y;                                 // column of the tile
@@ -189,7 +210,7 @@ __global__ __launch_bounds__(256) void k_gp_ks_tile(const GpModelDev g, const Gp
         r2 += t * t;
     }
     double r, e;
-    matern_terms(3.0 * r2, r, e);
+    matern_terms(3.0 * r2, r, e, exptab);
     Ks[i + (long long)j * g.n] = g.amp * (1.0 + r) * e;
 }
 
@@ -281,6 +302,8 @@ __global__ __launch_bounds__(64 * GPV_WAVES) void k_gp_var_fused(const GpModelDe
     __shared__ double Bs[4][GPV_KB * GPV_CELLS];        // two phases (double buffer) x two batches per phase
     auto bs_index = [](int kk, int cell) { return (((kk >> 2) * 4 + (cell >> 4)) * 4 + (kk & 3)) * 16 + (cell & 15); };
     __shared__ double part[GPV_WAVES][GPV_CELLS];
+    __shared__ double exptab[64];
+    gp_exp_table_to_lds(exptab);
     const int n = g.n;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long w = a.L.Ny + 2, ncell = (long long)(a.L.Nx + 2) * w;
@@ -316,7 +339,7 @@ __global__ __launch_bounds__(64 * GPV_WAVES) void k_gp_var_fused(const GpModelDe
                 r2 += t * t;
             }
             double r, e;
-            matern_terms(3.0 * r2, r, e);
+            matern_terms(3.0 * r2, r, e, exptab);
             val = g.amp * (1.0 + r) * e;
         }
 #endif
@@ -421,6 +444,8 @@ template <int D>
 __global__ __launch_bounds__(256) void k_gp_nll_grad(const double* __restrict__ X, const double* __restrict__ alpha, const double* __restrict__ Kinv,
                                                      int n, int m, double amp, const double* __restrict__ inv_scale, double* __restrict__ partial) {
     __shared__ double red[4][1 + D];
+    __shared__ double exptab[64];
+    gp_exp_table_to_lds(exptab);
     const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
     double acc[1 + D];
     for (int k = 0; k <= D; ++k) acc[k] = 0.0;
@@ -432,7 +457,7 @@ __global__ __launch_bounds__(256) void k_gp_nll_grad(const double* __restrict__ 
             r2 += t[k];
         }
         double r, e;
-        matern_terms(3.0 * r2, r, e);
+        matern_terms(3.0 * r2, r, e, exptab);
         double w = -(double)m * Kinv[i + (long long)j * n];
         for (int o = 0; o < m; ++o) w = fma(alpha[i + (long long)o * n], alpha[j + (long long)o * n], w);
         acc[0] = w * (amp * (1.0 + r) * e);
@@ -455,6 +480,8 @@ __global__ __launch_bounds__(256) void k_gp_nll_grad(const double* __restrict__ 
 template <int D>
 __global__ void k_gp_nll_matrix(const double* __restrict__ X, int n, double amp, const double* __restrict__ inv_scale, double sigma2,
                                 double* __restrict__ K) {
+    __shared__ double exptab[64];
+    gp_exp_table_to_lds(exptab);
     const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
     if (i >= n) return;
     double r2 = 0.0;
@@ -463,7 +490,7 @@ __global__ void k_gp_nll_matrix(const double* __restrict__ X, int n, double amp,
         r2 += dz * dz;
     }
     double r, e;
-    matern_terms(3.0 * r2, r, e);
+    matern_terms(3.0 * r2, r, e, exptab);
     K[i + (long long)j * n] = amp * (1.0 + r) * e + (i == j ? sigma2 : 0.0);
 }
 
