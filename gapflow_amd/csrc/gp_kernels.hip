@@ -71,20 +71,28 @@ __device__ __forceinline__ void gp_exp_table_to_lds(double* tab) {
 // Matern-3/2 pieces for t = 3 r^2 >= 0:  s = sqrt(t),  e = exp(-s);  k = A (1 + s) e,  dk/ds ~ s e.
 // These kernels are bound by the fp64 units (on gfx950 only the double-precision operations cost four cycles per wave; moves,
 // integer operations and LDS reads ride along), so the NUMBER of fp64 operations of this function is their speed:
-//   * sqrt: v_rsq_f64 + two Goldschmidt steps (8 operations) instead of the range-scaled library sqrt;
+//   * sqrt: v_rsq_f64 + one Halley step (5 operations) instead of the range-scaled library sqrt;
 //   * exp (argument <= 0): reduction by ln2/64 (round to nearest, hi/lo split), a 64-entry table of 2^(j/64) in LDS, a
 //     degree-5 polynomial and v_ldexp_f64 -- 12 operations instead of the 19 of a degree-13 polynomial after a reduction by ln 2
 //     (and far fewer than the library exp with its overflow / underflow selects).
-// Accurate to 1.5 ulp (exp) and 1 ulp (sqrt) on the range that matters; every kernel below (K, Ks, mean, variance, likelihood)
+// Accurate to 1.5 ulp (exp) and 1.5 ulp (sqrt) on the range that matters; every kernel below (K, Ks, mean, variance, likelihood)
 // uses this one function, so K and Ks stay consistent.
 __device__ __forceinline__ void matern_terms(double t, double& s, double& e, const double* __restrict__ tab) {
     const double tt = fmax(t, 1e-300);                      // t = 0 -> s = 1e-150, k = A exactly
     const double y = __builtin_amdgcn_rsq(tt);              // ~24-bit seed
+#ifdef GPF_GP_GOLDSCHMIDT_SQRT  // (A/B: two Goldschmidt steps, 7 operations, 1.1 ulp)
     double g = tt * y, h = 0.5 * y;
     double r = fma(-h, g, 0.5);
     g = fma(g, r, g); h = fma(h, r, h);
     r = fma(-h, g, 0.5);
     s = fma(g, r, g);
+#else
+    // one Halley step: with c = t y^2 = 1 + O(2^-24), sqrt(t) = t y (15/8 - 5/4 c + 3/8 c^2) (1 + O(2^-72)): 5 operations, 1.5 ulp
+    const double g = tt * y, c = g * y;
+    double q = fma(0.375, c, -1.25);
+    q = fma(q, c, 1.875);
+    s = g * q;
+#endif
     const double x = -fmin(s, 800.0);                       // exp(-800) = 0 in fp64 anyway
     const double n = __builtin_rint(x * 92.332482616893657);            // 64 / ln 2
     double f = fma(n, -0.010830424693267560, x);            // ln2 / 64 = hi + lo; hi = (ln2 hi) / 64 keeps its 21 trailing zero bits
