@@ -93,7 +93,9 @@ __device__ __forceinline__ void matern_terms(double t, double& s, double& e, con
     q = fma(q, c, 1.875);
     s = g * q;
 #endif
-    const double x = -fmin(s, 800.0);                       // exp(-800) = 0 in fp64 anyway
+    // exp(-800) = 0 in fp64 anyway; the clamp keeps the reduction exact (n < 2^21) and the integer conversion in range for the
+    // absurd distances a line-search probe of the training can produce (unclamped, t > 1e14 returned inf: tools/matern_accuracy.hip)
+    const double x = -fmin(s, 800.0);
     const double n = __builtin_rint(x * 92.332482616893657);            // 64 / ln 2
     double f = fma(n, -0.010830424693267560, x);            // ln2 / 64 = hi + lo; hi = (ln2 hi) / 64 keeps its 21 trailing zero bits
     f = fma(n, -2.9815858269852933e-12, f);
