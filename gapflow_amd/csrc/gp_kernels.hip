@@ -277,7 +277,8 @@ __global__ __launch_bounds__(1024) void k_gp_var_tile(const double* V, int n, in
 // 64 cells:
 //   * the Matern values k(Z_k, z*_j) of 32 training points x 64 cells at a time are produced on the vector ALUs straight
 //     into LDS (each wave: its lane's cell against 2 wave-uniform training points, 2 evaluations per lane and batch),
-//     double-buffered, one barrier per batch;
+//     double-buffered; batch p is multiplied in the same phase as batch 15 - p (the order of the columns of a sum is free),
+//     so every phase holds the same work and no wave idles through the late, nearly empty batches; one barrier per phase;
 //   * V = L^-1 Ks runs on the matrix cores (v_mfma_f64_16x16x4_f64; A operand = L^-1 rows straight from L2 -- the 2 MB
 //     factor stays resident there --, B operand = the LDS tile, accumulators never leave the registers).  L^-1 is lower
 //     triangular: a 16-row tile t has nothing to multiply beyond column 16 t + 15.  Wave w owns tiles w and 31 - w: 52 % of
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(1024) void k_gp_var_tile(const double* V, int n, in
 // 14.9 ms of matrix-pipe time (SQ_VALU_MFMA_BUSY_CYCLES); the rest cannot hide behind them: on this chip the f64 matrix
 // instruction and the f64 vector ALU are the same units -- every fp64 VALU instruction between two MFMAs lengthens the pair
 // by its own 4+ cycles (tools/mfma_f64_probe.hip: 78 TFLOP/s with nothing in between, 55 with six FMAs, 43 with twelve) --
-// so the Matern values (40 fp64 instructions each) and the operand selects are paid in full.  Tried and dropped: 8 waves
+// so the Matern values (~30 fp64 operations each) and the operand selects are paid in full.  Tried and dropped: 8 waves
 // with four tiles each (250 registers; prefetched or not: 27-30 ms), 64-column batches (no change), unconditional
 // prefetched A loads in straight-line half batches (exact s_waitcnt counts, but 128 registers per wave at 16 waves per
 // workgroup do not hold them: scratch spills, 93 ms).
@@ -299,8 +300,9 @@ constexpr int GPV_WAVES = 16;                       // waves per workgroup
 constexpr int GPV_TPW = 32 / GPV_WAVES;             // 16-row tiles of L^-1 per wave
 #ifndef GPV_KU
 #define GPV_KU 4                                    // k-steps (of 4 columns) whose A operands are requested together: 1, 2 or 4
-#endif                                              // (27.0 / 24.9 / 24.4 ms before the changes below; 4 needs the 20 VGPRs that
-                                                    // the exp coefficients occupied as literals, see gp_exp_coef)
+#endif                                              // (27.0 / 24.9 / 24.4 ms; with 4 the kernel sits at 112-118 of the 128
+                                                    // registers a wave of a 16-wave workgroup can have -- tests/test_step_isa.py
+                                                    // fails on any scratch use here)
 typedef double gpv_acc __attribute__((ext_vector_type(4)));
 
 template <int D>
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(64 * GPV_WAVES) void k_gp_var_fused(const GpModelDe
                                                                  double yscale2, double* __restrict__ var_plane, double* __restrict__ blockmax) {
     // B tile of a batch, laid out the way the MFMA reads it: the 64 lanes of one read -- (k mod 4, cell mod 16) for a fixed
     // k-step and 16-cell tile -- are 64 consecutive doubles.  (Row-major [k][cell] put the four k rows of a read 512 bytes
-    // apart, on the same banks: four-way conflicts on every read made the LDS the co-critical resource, 10 of 26 ms.)
+    // apart, on the same banks: four-way conflicts on every read, 2 % of the kernel.)
     __shared__ double Bs[4][GPV_KB * GPV_CELLS];        // two phases (double buffer) x two batches per phase
     auto bs_index = [](int kk, int cell) { return (((kk >> 2) * 4 + (cell >> 4)) * 4 + (kk & 3)) * 16 + (cell & 15); };
     __shared__ double part[GPV_WAVES][GPV_CELLS];
