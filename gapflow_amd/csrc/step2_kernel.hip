@@ -51,6 +51,15 @@ constexpr int STRIP2 = 126;     // output columns per wavefront
 #ifndef GPF_K2_MINWAVES_LINE
 #define GPF_K2_MINWAVES_LINE GPF_K2_MINWAVES    // ... for the x-only-gap kernels (half the row buffers)
 #endif
+// Instantiations whose closures need more than the 256 registers of two waves per SIMD -- the equations of state that go through
+// pow / exp / log (power law, Murnaghan-Tait, BWR, Bayada-Chupin) and the slip-length field together with piezo-viscosity --
+// are compiled for ONE wave per SIMD (512 registers): held to 256 they spill into the march loop, which both costs the
+// scratch traffic and makes hipcc drain the pipelined row loads (4096^2, Murnaghan-Tait: 535 us per step).  They also request
+// fewer rows ahead.  plan_step2 reads the occupancy back and sizes the row chunks for it.
+template <int EOS, bool HAS_LS, bool PIEZO>
+struct Step2Weight {
+    static constexpr bool heavy = EOS == EOS_PL || EOS == EOS_MT || EOS == EOS_BWR || EOS == EOS_BAYADA || (HAS_LS && PIEZO);
+};
 
 // Where the windows sit, per predictor direction (host: strip2_geom in api.hip).
 //   logical column of window position p of strip s:  m = w0 + 126 s + p,  p = 2 lane + slot
@@ -277,7 +286,8 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
         if (HAS_LS) asm_load16(r.ls[0], (dummy ? lane_q : lane_ls) + rb);
     };
     // wait until row r has landed: exactly AHEAD row requests (NL loads each) have been issued after it
-    constexpr int AHEAD_ROWS = PIEZO ? 1 : ((TOPO == 1 || TOPO == 3) ? GPF_K2_AHEAD_LINE : GPF_K2_AHEAD);
+    constexpr bool HEAVY = Step2Weight<EOS, HAS_LS, PIEZO>::heavy;
+    constexpr int AHEAD_ROWS = PIEZO ? 1 : ((TOPO == 1 || TOPO == 3) ? (HEAVY ? 2 : GPF_K2_AHEAD_LINE) : GPF_K2_AHEAD);
     auto arrive = [&](Raw& r) {
         asm_wait3<AHEAD_ROWS * NL>(r.q[0], r.q[1], r.q[2]);
         if (TOPO == 0) asm_wait3<AHEAD_ROWS * NL>(r.t[0], r.t[1], r.t[2]);
@@ -642,7 +652,8 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
 // device-side step counter.  Grid: gridDim.x = a multiple of 8 blocks of 4 waves; wave w of the XCD-ordered numbering
 // works on strip w % nstrips of chunk w / nstrips.
 template <int EOS, bool HAS_LS, bool PIEZO, int D, int TOPO>
-__global__ __launch_bounds__(256, ((TOPO == 1 || TOPO == 3) ? GPF_K2_MINWAVES_LINE : GPF_K2_MINWAVES)) void k_step2(const Step2Args a, const Phys P) {
+__global__ __launch_bounds__(256, (Step2Weight<EOS, HAS_LS, PIEZO>::heavy ? 1 : ((TOPO == 1 || TOPO == 3) ? GPF_K2_MINWAVES_LINE : GPF_K2_MINWAVES)))
+void k_step2(const Step2Args a, const Phys P) {
     __shared__ double stash[4][3][128];         // per wave: stage-1 field on the downwind ghost row (fused)
     __shared__ Acc red_sm[4];
     __shared__ int s_last;
