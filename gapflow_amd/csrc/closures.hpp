@@ -124,6 +124,60 @@ GPF_HD void viscous_general(int where, const double q[3], const double hh[3], co
     out[5] = eta * (uy + vx);
 }
 
+// ---- pow for the equations of state ---------------------------------------------------------------------------
+// The library pow costs a few hundred fp64 operations (extended-precision log, special cases): with three of them per
+// cell-update the Murnaghan-Tait and power-law steps were compute-bound at three times the Dowson-Higginson step time.
+// For the operands an equation of state sees (x > 0 a density ratio, |y ln x| far below 700) a plain exp(y ln x) is
+// accurate to a few 1e-16 |y ln x|: ln through the mantissa in [1/sqrt2, sqrt2) and the atanh series (11 terms), exp by
+// reduction with ln 2 and a degree-13 polynomial -- about 45 operations.  The host build (tests/hostcheck) keeps std::pow.
+GPF_HD double fast_log(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int e;
+    double m = __builtin_frexp(x, &e);                      // m in [0.5, 1)
+    const bool low = m < 0.70710678118654752;
+    m = low ? m + m : m;                                    // [1/sqrt2, sqrt2)
+    e = low ? e - 1 : e;
+    const double z = (m - 1.0) * rcp(m + 1.0);              // |z| <= 0.1716
+    const double w = z * z;
+    double p = 1.0 / 23.0;
+    p = fma(p, w, 1.0 / 21.0); p = fma(p, w, 1.0 / 19.0); p = fma(p, w, 1.0 / 17.0); p = fma(p, w, 1.0 / 15.0);
+    p = fma(p, w, 1.0 / 13.0); p = fma(p, w, 1.0 / 11.0); p = fma(p, w, 1.0 / 9.0); p = fma(p, w, 1.0 / 7.0);
+    p = fma(p, w, 1.0 / 5.0); p = fma(p, w, 1.0 / 3.0);
+    const double lm = fma(z + z, p * w, z + z);             // ln m = 2 z (1 + w p)
+    const double de = (double)e;
+    return fma(de, 0.69314718036912382, fma(de, 1.9082149292705877e-10, lm));      // e ln2 (hi + lo) + ln m
+#else
+    return log(x);
+#endif
+}
+
+GPF_HD double fast_exp(double t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double tc = fmin(fmax(t, -745.0), 709.0);
+    const double n = __builtin_rint(tc * 1.4426950408889634);
+    double f = fma(n, -0.69314718036912382, tc);
+    f = fma(n, -1.9082149292705877e-10, f);
+    double p = 1.6059043836821613e-10;
+    p = fma(p, f, 2.08767569878681e-09); p = fma(p, f, 2.505210838544172e-08); p = fma(p, f, 2.755731922398589e-07);
+    p = fma(p, f, 2.7557319223985893e-06); p = fma(p, f, 2.48015873015873e-05); p = fma(p, f, 1.984126984126984e-04);
+    p = fma(p, f, 1.388888888888889e-03); p = fma(p, f, 8.333333333333333e-03); p = fma(p, f, 4.1666666666666664e-02);
+    p = fma(p, f, 1.6666666666666666e-01); p = fma(p, f, 0.5); p = fma(p, f, 1.0); p = fma(p, f, 1.0);
+    return ldexp(p, (int)n);
+#else
+    return exp(t);
+#endif
+}
+
+// x^y for x > 0 (anything else: NaN, like np.power of a negative base with a fractional exponent)
+GPF_HD double pow_pos(double x, double y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double r = fast_exp(y * fast_log(x));
+    return x > 0.0 ? r : __builtin_nan("");
+#else
+    return pow(x, y);
+#endif
+}
+
 // ---- equations of state -------------------------------------------------------------------
 
 template <int EOS>
@@ -135,14 +189,14 @@ GPF_HD double eos_pressure(double rho, const Phys& P) {
         return P.e[1] + (P.e[2] * (s - 1.0)) * rcp(P.e[3] - s);
     } else if (EOS == EOS_PL) {
         // e0=rho0 e1=P0 e2=alpha e3=1/(1-alpha/2)
-        return P.e[1] * pow(rho / P.e[0], P.e[3]);
+        return P.e[1] * pow_pos(rho / P.e[0], P.e[3]);
     } else if (EOS == EOS_VDW) {
         // e0=1000/M e1=R*T e2=a/10 e3=b/1000
         double md = rho * P.e[0];
         return P.e[1] * md / (1.0 - P.e[3] * md) - P.e[2] * md * md;
     } else if (EOS == EOS_MT) {
         // e0=rho0 e1=P0 e2=K e3=n
-        return P.e[2] / P.e[3] * (pow(rho / P.e[0], P.e[3]) - 1.0) + P.e[1];
+        return P.e[2] / P.e[3] * (pow_pos(rho / P.e[0], P.e[3]) - 1.0) + P.e[1];
     } else if (EOS == EOS_CUBIC) {
         return ((P.e[0] * rho + P.e[1]) * rho + P.e[2]) * rho + P.e[3];
     } else if (EOS == EOS_BWR) {
@@ -154,14 +208,14 @@ GPF_HD double eos_pressure(double rho, const Phys& P) {
         double ex = P.x[14];
         for (int k = 13; k >= 9; --k) ex = ex * r2 + P.x[k];
         ex *= r2 * rho;
-        return poly + exp(-P.e[0] * r2) * ex;
+        return poly + fast_exp(-P.e[0] * r2) * ex;
     } else {
         // Bayada-Chupin: e0=rho_l e1=rho_v e2=c_l^2 e3=c_v^2 e4=N e5=Pcav e6=1/(rho_v-rho_l)
         double alpha = (rho - P.e[0]) * P.e[6];
         if (alpha < 0.0) return P.e[5] + (rho - P.e[0]) * P.e[2];
         if (alpha <= 1.0) {
             double den = P.e[0] * (P.e[1] * P.e[3] * (1.0 - alpha) + P.e[0] * P.e[2] * alpha);
-            return P.e[5] + P.e[4] * log(P.e[1] * P.e[3] * rho / den);
+            return P.e[5] + P.e[4] * fast_log(P.e[1] * P.e[3] * rho / den);
         }
         return P.e[3] * rho;
     }
@@ -176,13 +230,14 @@ GPF_HD double eos_c2(double rho, const Phys& P) {
         return P.e[6] * (it * it);                    // e6 = C1*rho0*(C2-1)
     } else if (EOS == EOS_PL) {
         // -2 P0 (rho/rho0)^(-2/(alpha-2)) / ((alpha-2) rho)
-        return -2.0 * P.e[1] * pow(rho / P.e[0], -2.0 / (P.e[2] - 2.0)) / ((P.e[2] - 2.0) * rho);
+        return -2.0 * P.e[1] * pow_pos(rho / P.e[0], -2.0 / (P.e[2] - 2.0)) / ((P.e[2] - 2.0) * rho);
     } else if (EOS == EOS_VDW) {
         double md = rho * P.e[0];
         double t = 1.0 - P.e[3] * md;
         return P.e[1] / (t * t) - 2.0 * P.e[2] * md;
     } else if (EOS == EOS_MT) {
-        return P.e[2] / pow(P.e[0], P.e[3]) * pow(rho, P.e[3] - 1.0);
+        // K / rho0^n rho^(n-1) = (K / rho0) (rho / rho0)^(n-1): one pow, of a ratio near one
+        return (P.e[2] / P.e[0]) * pow_pos(rho / P.e[0], P.e[3] - 1.0);
     } else if (EOS == EOS_CUBIC) {
         return (3.0 * P.e[0] * rho + 2.0 * P.e[1]) * rho + P.e[2];
     } else if (EOS == EOS_BWR) {
@@ -198,7 +253,7 @@ GPF_HD double eos_c2(double rho, const Phys& P) {
         }
         ex *= r2 * rho;     // E
         dex *= r2;          // E'
-        double g = exp(-P.e[0] * r2);
+        double g = fast_exp(-P.e[0] * r2);
         return dpoly + g * dex - 2.0 * rho * P.e[0] * g * ex;
     } else {
         double alpha = (rho - P.e[0]) * P.e[6];
@@ -214,8 +269,8 @@ GPF_HD double eos_c2(double rho, const Phys& P) {
 // `arg` is the pressure, or the density when the EOS is Bayada-Chupin (stress.py:307-310)
 GPF_HD double piezo_eta(double eta0, double arg, const Phys& P) {
     switch (P.piezo) {
-    case PIEZO_BARUS:    return eta0 * exp(P.pz[0] * arg);
-    case PIEZO_ROELANDS: return eta0 * exp(P.pz[3] * (-1.0 + pow(1.0 + arg / P.pz[1], P.pz[2])));   // pz3 = ln(mu0/mu_inf)
+    case PIEZO_BARUS:    return eta0 * fast_exp(P.pz[0] * arg);
+    case PIEZO_ROELANDS: return eta0 * fast_exp(P.pz[3] * (-1.0 + pow_pos(1.0 + arg / P.pz[1], P.pz[2])));   // pz3 = ln(mu0/mu_inf)
     case PIEZO_DUKLER: {
         double a = (arg - P.pz[1]) / (P.pz[2] - P.pz[1]);
         return a * P.pz[0] + (1.0 - a) * eta0;
