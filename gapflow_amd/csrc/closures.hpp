@@ -188,15 +188,15 @@ GPF_HD double eos_pressure(double rho, const Phys& P) {
         double s = r * P.e[5];
         return P.e[1] + (P.e[2] * (s - 1.0)) * rcp(P.e[3] - s);
     } else if (EOS == EOS_PL) {
-        // e0=rho0 e1=P0 e2=alpha e3=1/(1-alpha/2)
-        return P.e[1] * pow_pos(rho / P.e[0], P.e[3]);
+        // e0=rho0 e1=P0 e2=alpha e3=1/(1-alpha/2) e5=1/rho0 e6=-2/(alpha-2) e7=-2 P0/(alpha-2)
+        return P.e[1] * pow_pos(rho * P.e[5], P.e[3]);
     } else if (EOS == EOS_VDW) {
         // e0=1000/M e1=R*T e2=a/10 e3=b/1000
         double md = rho * P.e[0];
-        return P.e[1] * md / (1.0 - P.e[3] * md) - P.e[2] * md * md;
+        return P.e[1] * md * rcp(1.0 - P.e[3] * md) - P.e[2] * md * md;
     } else if (EOS == EOS_MT) {
-        // e0=rho0 e1=P0 e2=K e3=n
-        return P.e[2] / P.e[3] * (pow_pos(rho / P.e[0], P.e[3]) - 1.0) + P.e[1];
+        // e0=rho0 e1=P0 e2=K e3=n e5=1/rho0 e6=K/n e7=K/rho0
+        return P.e[6] * (pow_pos(rho * P.e[5], P.e[3]) - 1.0) + P.e[1];
     } else if (EOS == EOS_CUBIC) {
         return ((P.e[0] * rho + P.e[1]) * rho + P.e[2]) * rho + P.e[3];
     } else if (EOS == EOS_BWR) {
@@ -215,7 +215,7 @@ GPF_HD double eos_pressure(double rho, const Phys& P) {
         if (alpha < 0.0) return P.e[5] + (rho - P.e[0]) * P.e[2];
         if (alpha <= 1.0) {
             double den = P.e[0] * (P.e[1] * P.e[3] * (1.0 - alpha) + P.e[0] * P.e[2] * alpha);
-            return P.e[5] + P.e[4] * fast_log(P.e[1] * P.e[3] * rho / den);
+            return P.e[5] + P.e[4] * fast_log(P.e[1] * P.e[3] * rho * rcp(den));
         }
         return P.e[3] * rho;
     }
@@ -230,14 +230,14 @@ GPF_HD double eos_c2(double rho, const Phys& P) {
         return P.e[6] * (it * it);                    // e6 = C1*rho0*(C2-1)
     } else if (EOS == EOS_PL) {
         // -2 P0 (rho/rho0)^(-2/(alpha-2)) / ((alpha-2) rho)
-        return -2.0 * P.e[1] * pow_pos(rho / P.e[0], -2.0 / (P.e[2] - 2.0)) / ((P.e[2] - 2.0) * rho);
+        return P.e[7] * pow_pos(rho * P.e[5], P.e[6]) * rcp(rho);
     } else if (EOS == EOS_VDW) {
         double md = rho * P.e[0];
         double t = 1.0 - P.e[3] * md;
-        return P.e[1] / (t * t) - 2.0 * P.e[2] * md;
+        return P.e[1] * rcp(t * t) - 2.0 * P.e[2] * md;
     } else if (EOS == EOS_MT) {
         // K / rho0^n rho^(n-1) = (K / rho0) (rho / rho0)^(n-1): one pow, of a ratio near one
-        return (P.e[2] / P.e[0]) * pow_pos(rho / P.e[0], P.e[3] - 1.0);
+        return P.e[7] * pow_pos(rho * P.e[5], P.e[3] - 1.0);
     } else if (EOS == EOS_CUBIC) {
         return (3.0 * P.e[0] * rho + 2.0 * P.e[1]) * rho + P.e[2];
     } else if (EOS == EOS_BWR) {
@@ -259,7 +259,7 @@ GPF_HD double eos_c2(double rho, const Phys& P) {
         double alpha = (rho - P.e[0]) * P.e[6];
         if (alpha < 0.0) return P.e[2];
         if (alpha <= 1.0)
-            return P.e[1] * P.e[0] * (P.e[3] * P.e[2]) / (alpha * P.e[0] * P.e[2] + (1.0 - alpha) * P.e[1] * P.e[3]) / rho;
+            return P.e[1] * P.e[0] * (P.e[3] * P.e[2]) * rcp((alpha * P.e[0] * P.e[2] + (1.0 - alpha) * P.e[1] * P.e[3]) * rho);
         return P.e[3];
     }
 }

@@ -22,11 +22,15 @@ inline void setup_phys(Phys& P, double U, double V, double eta, double zeta, dou
         break;
     case EOS_PL:     // rho0, P0, alpha
         P.e[0] = e[0]; P.e[1] = e[1]; P.e[2] = e[2]; P.e[3] = 1.0 / (1.0 - 0.5 * e[2]);
+        P.e[5] = 1.0 / e[0]; P.e[6] = -2.0 / (e[2] - 2.0); P.e[7] = -2.0 * e[1] / (e[2] - 2.0);       // 1/rho0, sound-speed exponent and prefactor
         break;
     case EOS_VDW:    // M, T, a, b   (pressure.py:168-173)
         P.e[0] = 1000.0 / e[0]; P.e[1] = 8.31446261815324 * e[1]; P.e[2] = e[2] / 10.0; P.e[3] = e[3] / 1000.0;
         break;
     case EOS_MT:     // rho0, P0, K, n
+        for (int i = 0; i < 4; ++i) P.e[i] = e[i];
+        P.e[5] = 1.0 / e[0]; P.e[6] = e[2] / e[3]; P.e[7] = e[2] / e[0];      // 1/rho0, K/n, K/rho0
+        break;
     case EOS_CUBIC:  // a, b, c, d
         for (int i = 0; i < 4; ++i) P.e[i] = e[i];
         break;
