@@ -333,9 +333,18 @@ def run_slabs(args, rank, world):
     import torch
     import torch.distributed as dist
     from gapflow_amd.slab import SlabProblem
-    local = int(os.environ.get('LOCAL_RANK', rank))
+    # GPF_BENCH_ONE_GPU_REHEARSAL=1 (development boxes with one GPU; at most 5 ranks there): every rank on device 0, the
+    # collectives staged through host memory over gloo -- RCCL refuses two ranks on one device.  Checks the launch path,
+    # the partition and the line; its numbers say nothing about xGMI and the line says so.
+    rehearsal = os.environ.get('GPF_BENCH_ONE_GPU_REHEARSAL') == '1'
+    local = 0 if rehearsal else int(os.environ.get('LOCAL_RANK', rank))
     torch.cuda.set_device(local)
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    if rehearsal:
+        from gapflow_amd.slab import HostStagedGroup
+        dist.init_process_group('gloo')
+        dist = HostStagedGroup(dist, torch)
+    else:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     cells = N_GRID * N_GRID
 
     def timed(prob, k):
@@ -367,13 +376,16 @@ def run_slabs(args, rank, world):
         }
 
     with contextlib.redirect_stdout(sys.stderr):
-        prob = SlabProblem.from_string(WORKLOAD_YAML.format(N=N_GRID), device=local)
+        prob = SlabProblem.from_string(WORKLOAD_YAML.format(N=N_GRID), device=local, dist=dist)
         prob.pre_run()
         prob.advance(args.warmup)
         wall = timed(prob, args.steps)
         st = prob.state()
         assert st.step == args.warmup + args.steps and st.invalid == 0, "steps were skipped inside the timed region"
-    best = line(wall, "host-dispatched steps, RCCL all-gather")
+    best = line(wall, "host-dispatched steps, RCCL all-gather" if not rehearsal else
+                "REHEARSAL on one GPU: all ranks share device 0, collectives staged through the host over gloo")
+    if rehearsal:
+        best["rehearsal_one_gpu"] = True
     st_ref = (int(st.step), float(st.dt), float(st.ekin))
 
     # Two faster ways to run the same K steps can follow (GPF_BENCH_TRY_P2P=1 / GPF_BENCH_TRY_GRAPH=1; both OFF by default:
@@ -436,7 +448,7 @@ def run_slabs(args, rank, world):
     def try_p2p():
         # the step's own kernels write rows and records into the peers' IPC-mapped mailboxes (gapflow_amd/slab.py)
         nonlocal best
-        p2 = SlabProblem.from_string(WORKLOAD_YAML.format(N=N_GRID), device=local)
+        p2 = SlabProblem.from_string(WORKLOAD_YAML.format(N=N_GRID), device=local, dist=dist)
         if not p2.connect_p2p():
             return
         p2.pre_run()
@@ -473,6 +485,25 @@ def run_slabs(args, rank, world):
     return best if rank == 0 else None
 
 
+def launch_ranks(args, real_stdout):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    as a child on 127.0.0.1 with a free port, pass its stdout (rank 0's JSON line) through, return its exit status."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    for ln in child.stdout:
+        real_stdout.write(ln)
+        real_stdout.flush()
+    return child.wait()
+
+
 _emit = lambda obj: print(json.dumps(obj), flush=True)
 _keep_alive = []
 
@@ -495,9 +526,13 @@ def main():
     os.dup2(2, 1)
     global _emit
     _emit = lambda obj: (real_stdout.write(json.dumps(obj) + '\n'), real_stdout.flush())
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # called as plain `python bench.py --gpus N`: start the N ranks ourselves.  A CHILD process (nothing here has touched
+        # the GPU yet, and nothing is re-exec'ed), its JSON line relayed, its exit status passed on.
+        raise SystemExit(launch_ranks(args, real_stdout))
     if args.gpus > 1 or world > 1:
         if world != args.gpus:
-            raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} ranks: launch with "
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
                              f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...")
         out = run_slabs(args, rank, world)
     else:

@@ -112,6 +112,132 @@ class LoopbackGroup:
         pass
 
 
+class HostStagedGroup:
+    """torch.distributed look-alike that moves GPU tensors through host memory over a CPU backend (gloo).
+
+    RCCL refuses two ranks on one device ("Duplicate GPU detected"), so on a one-GPU box the multi-rank behaviour of the
+    HIP slab engine (halo kinds, seam topography, message rows, rank-ordered commit) is rehearsed with a few processes
+    sharing the GPU and this transport (tests/test_gpu_slab.py, bench.py with GPF_BENCH_ONE_GPU_REHEARSAL=1)."""
+
+    def __init__(self, dist, torch):
+        self._d, self._t = dist, torch
+        self.ReduceOp = dist.ReduceOp
+
+    def get_rank(self):
+        return self._d.get_rank()
+
+    def get_world_size(self):
+        return self._d.get_world_size()
+
+    def all_gather_into_tensor(self, out, inp):
+        self._t.cuda.synchronize()
+        o, i = out.cpu(), inp.cpu()
+        self._d.all_gather_into_tensor(o, i)
+        out.copy_(o)
+
+    def all_reduce(self, t, op=None):
+        c = t.cpu()
+        self._d.all_reduce(c, op=op if op is not None else self.ReduceOp.SUM)
+        t.copy_(c)
+
+    def broadcast_object_list(self, box, src=0):
+        self._d.broadcast_object_list(box, src=src)
+
+    def barrier(self):
+        self._d.barrier()
+
+    def destroy_process_group(self):
+        self._d.destroy_process_group()
+
+
+class ThreadWorld:
+    """N ranks as N THREADS of one process, all on one GPU: `run(fn)` calls fn(group) once per rank, each with its own
+    torch.distributed look-alike whose collectives meet at thread barriers and move data with device copies.
+
+    What it is for: the test boxes allow six processes on a card, so an 8-rank decomposition (BASELINE.json configs[4], the
+    8-slab strong-scaling run) cannot be rehearsed with one process per rank there.  Every rank is a real SlabProblem with
+    its own library handle, partition, halo kinds, seam topography and messages; only the transport is stood in for.  All
+    ranks enqueue on the device's default stream, so "every rank has enqueued its part" (a thread barrier) is all the
+    ordering a collective needs.  All-gather transport only: the mailbox kernels poll for their peers and would wait for
+    launches queued behind them on the shared stream."""
+
+    class ReduceOp:
+        SUM, MAX, MIN = 'sum', 'max', 'min'
+
+    def __init__(self, world, torch):
+        import threading
+        self.world, self.torch = world, torch
+        self._barrier = threading.Barrier(world)
+        self._slots = [None] * world
+
+    class _Group:
+        def __init__(self, w, rank):
+            self._w, self._rank = w, rank
+            self.ReduceOp = ThreadWorld.ReduceOp
+
+        def get_rank(self):
+            return self._rank
+
+        def get_world_size(self):
+            return self._w.world
+
+        def barrier(self):
+            self._w._barrier.wait()
+
+        def all_gather_into_tensor(self, out, inp):
+            w = self._w
+            w._slots[self._rank] = inp
+            w._barrier.wait()                           # every rank's producers are enqueued
+            parts = out.view(w.world, -1)
+            for r in range(w.world):
+                parts[r].copy_(w._slots[r].view(-1))
+            w._barrier.wait()                           # every rank's copies are enqueued: the inputs may change again
+
+        def all_reduce(self, t, op=None):
+            w, torch = self._w, self._w.torch
+            w._slots[self._rank] = t.clone()
+            w._barrier.wait()
+            stack = torch.stack([w._slots[r] for r in range(w.world)])      # rank order on every rank
+            res = stack.sum(0) if op in (None, 'sum') else (stack.max(0).values if op == 'max' else stack.min(0).values)
+            w._barrier.wait()
+            t.copy_(res)
+
+        def broadcast_object_list(self, box, src=0):
+            w = self._w
+            if self._rank == src:
+                w._slots[src] = list(box)
+            w._barrier.wait()
+            box[:] = w._slots[src]
+            w._barrier.wait()
+
+    def run(self, fn):
+        """fn(group) on every rank; returns the results in rank order.  The first exception breaks the barriers (the other
+        ranks then fail at their next collective) and is re-raised."""
+        import threading
+        results, errors = [None] * self.world, []
+
+        def body(rank):
+            try:
+                if self.torch.cuda.is_available():
+                    self.torch.cuda.set_device(0)
+                results[rank] = fn(ThreadWorld._Group(self, rank))
+            except threading.BrokenBarrierError:
+                pass
+            except BaseException as e:      # noqa: BLE001
+                errors.append((rank, e))
+                self._barrier.abort()
+
+        threads = [threading.Thread(target=body, args=(r,), name=f'slab-rank-{r}') for r in range(self.world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            rank, e = sorted(errors, key=lambda x: x[0])[0]
+            raise RuntimeError(f"rank {rank} of the thread world failed: {type(e).__name__}: {e}") from e
+        return results
+
+
 class SlabDriver:
     """Runs the split step of an engine: step_local -> ONE all-gather -> commit.
 

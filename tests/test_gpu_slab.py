@@ -51,34 +51,9 @@ def test_one_rank_group_equals_serial_problem(hiplib, graph, monkeypatch):
         dist.destroy_process_group()
 
 
-class StagedGloo:
-    """torch.distributed look-alike that moves GPU tensors through host memory over gloo.
-
-    RCCL refuses two ranks on one device ("Duplicate GPU detected"), so on a 1-GPU box the multi-rank
-    behaviour of the HIP slab engine (halo kinds, seam topography, pack/scatter, rank-ordered commit) is
-    exercised with 2-3 processes sharing the GPU and this transport; the RCCL transport itself is the
-    stock torch.distributed code path checked by tests/test_slab_gloo.py."""
-
-    def __init__(self, dist, torch):
-        self._d, self._t = dist, torch
-        self.ReduceOp = dist.ReduceOp
-
-    def get_rank(self):
-        return self._d.get_rank()
-
-    def get_world_size(self):
-        return self._d.get_world_size()
-
-    def all_gather_into_tensor(self, out, inp):
-        self._t.cuda.synchronize()
-        o, i = out.cpu(), inp.cpu()
-        self._d.all_gather_into_tensor(o, i)
-        out.copy_(o)
-
-    def all_reduce(self, t, op=None):
-        c = t.cpu()
-        self._d.all_reduce(c, op=op)
-        t.copy_(c)
+# RCCL refuses two ranks on one device ("Duplicate GPU detected"): on a 1-GPU box the multi-rank behaviour of the HIP slab
+# engine is exercised with 2-3 processes sharing the GPU and collectives staged through host memory over gloo.
+from gapflow_amd.slab import HostStagedGroup as StagedGloo      # noqa: E402
 
 
 def _slab_worker(rank, world, port, text, nsteps, out_dir, p2p=False):

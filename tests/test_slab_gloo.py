@@ -178,6 +178,55 @@ def test_slabs_reproduce_the_serial_run(tmp_path, text, world):
     assert covered == list(range(1, 38 if text is PERIODIC else 31))
 
 
+@pytest.mark.parametrize('text', [PERIODIC, DIRICHLET], ids=['periodic', 'dirichlet'])
+def test_eight_ranks_in_one_process_reproduce_the_serial_run(text):
+    """gapflow_amd.slab.ThreadWorld (eight ranks as threads of one process: how the GPU tests rehearse the 8-slab runs on a
+    box that allows six processes on its card) drives the same SlabDriver / engine protocol as the gloo groups above."""
+    import torch
+    from gapflow_amd.slab import SlabLayout, SlabDriver, ThreadWorld
+    from oracle.config import read_yaml_input
+    from oracle.problem import OracleProblem
+    nsteps, world = 12, 8
+    ref = OracleProblem.from_dict(read_yaml_input(io.StringIO(text)))
+    ref._pre_run()
+    dt0, ekin0 = ref.dt, ref.kinetic_energy_old
+    for _ in range(nsteps):
+        ref.update()
+
+    def rank_body(group):
+        d = read_yaml_input(io.StringIO(text))
+        layout = SlabLayout(d['grid'], group.get_rank(), world)
+        engine = OracleSlabEngine(d, layout, torch)
+        engine.pre_run(dt0, ekin0)
+        SlabDriver(engine, layout, group, torch).advance(nsteps)
+        t = torch.tensor([float(group.get_rank())], dtype=torch.float64)
+        group.all_reduce(t, op=group.ReduceOp.MAX)
+        assert float(t) == world - 1
+        return layout, engine.p.q.copy(), engine.p.dt, engine.p.residual
+
+    covered = []
+    for layout, q, dt, res in ThreadWorld(world, torch).run(rank_body):
+        for c in range(3):
+            assert np.abs(q[c] - ref.q[c, layout.rows()]).max() <= 1e-11 * np.abs(ref.q[c]).max(), f'rank {layout.rank} component {c}'
+        np.testing.assert_allclose(dt, ref.dt, rtol=1e-12)
+        np.testing.assert_allclose(res, ref.residual, rtol=1e-6, atol=1e-10)
+        covered += list(range(layout.lo, layout.hi + 1))
+    assert covered == list(range(1, ref.grid['Nx'] + 1))
+
+
+def test_thread_world_reports_the_failing_rank():
+    import torch
+    from gapflow_amd.slab import ThreadWorld
+
+    def body(group):
+        if group.get_rank() == 2:
+            raise ValueError('boom')
+        group.barrier()
+
+    with pytest.raises(RuntimeError, match='rank 2 .* boom'):
+        ThreadWorld(4, torch).run(body)
+
+
 def test_partition_and_layout():
     from gapflow_amd.slab import partition, SlabLayout
     from gapflow_amd.io import sanitize_grid
