@@ -8,13 +8,15 @@ scalars and the device-side dt/residual update) of BASELINE.json configs[2]: 2-D
 4096 x 4096, Dowson-Higginson EOS, all-periodic, adaptive CFL 0.5.  The field is
 resident in HBM before the timed region; `value` = Nx*Ny*K / t in Mcell-updates/s over all ranks.
 
-For N > 1 the driver launches this file under torch.distributed.run, one rank per GPU; the grid
-is cut into N x-slabs (strong scaling: the 4096^2 problem is fixed) with one halo-row exchange
-and one 64-byte all-gather per step over RCCL.
+For N > 1 one rank runs per GPU -- under the driver's torch.distributed.run, or started by this file itself as a child
+process when it is called as plain `python bench.py --gpus N`; the grid is cut into N x-slabs (strong scaling: the 4096^2
+problem is fixed) with one all-gather per step over RCCL (2 halo rows + a 64-byte record per rank).
 
 Extra objects on the JSON line:
-  roofline     -- dominant kernel (k_step): algorithmic bytes (72 B x cells per launch) / its mean
-                  launch duration from HIP events on the launch stream, against 8 TB/s HBM3E.
+  roofline     -- dominant kernel (k_step2, the fused step in one launch): bytes COMPULSORY for this workload per launch
+                  (48 B x cells: the journal gap varies along x only, so the topography is one triple per row;
+                  `frac_survey_8d` prices the same launch at SURVEY.md 8(d)'s 72 B) / its mean launch duration from
+                  HIP events on the launch stream, against 8 TB/s HBM3E.
   cpu_baseline -- the NumPy oracle (oracle/, a restatement of the reference's CPU path) timed on
                   this host on a bounded sample of the same workload.
 """

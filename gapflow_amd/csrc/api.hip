@@ -93,10 +93,12 @@ struct gpf_handle {
     struct GpHost {
         bool set = false;
         GpModelDev dev;
-        double *Z = nullptr, *alpha = nullptr, *L = nullptr, *Linv = nullptr;
+        double *Z = nullptr, *alpha = nullptr, *L = nullptr, *Linv = nullptr, *W = nullptr;      // W: work matrix (L^-T)
         int cap = 0;                            // training points the buffers can hold (grown in steps of 128)
         bool has_linv = false;
         double xscale0 = 1.0;
+        double inv_scale[GP_MAX_D] = {};        // kernel length scales of the fit (fscale = inv_scale / x_scale)
+        double yscale_fit = 1.0;                // output scale at the fit (dev.yscale may be updated: gpf_gp_set_scales)
     } gp[3];
     // The sound-speed pass that closes a stage-wise step (d mean / d rho of the pressure surrogate on the new state) also
     // leaves the posterior MEAN of that state here; the first closure evaluation of the next step -- same state, same model --
@@ -278,7 +280,7 @@ extern "C" int gpf_destroy(gpf_handle* h) {
     void* ptrs[] = {h->q[0], h->q[1], h->topo, h->topo_line, h->Ls, h->g1, h->seam, h->halo, h->beyond, h->st, h->partials, h->arrive, h->block_partials, h->spart,
                     h->log, h->stage, h->fields, h->work, h->gpvar, h->gp_state_mean, h->gpscratch, h->gptile,
                     h->gp[0].Z, h->gp[0].alpha, h->gp[0].L, h->gp[1].Z, h->gp[1].alpha, h->gp[1].L,
-                    h->gp[2].Z, h->gp[2].alpha, h->gp[2].L, h->gp[0].Linv, h->gp[1].Linv, h->gp[2].Linv};
+                    h->gp[2].Z, h->gp[2].alpha, h->gp[2].L, h->gp[0].Linv, h->gp[1].Linv, h->gp[2].Linv, h->gp[0].W, h->gp[1].W, h->gp[2].W};
     if (h->blas && roclibs().ok) roclibs().destroy(h->blas);
     if (h->el.plan_f) fftlib().destroy(h->el.plan_f);
     if (h->el.plan_b) fftlib().destroy(h->el.plan_b);

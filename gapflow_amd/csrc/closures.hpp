@@ -129,9 +129,14 @@ GPF_HD void viscous_general(int where, const double q[3], const double hh[3], co
 // cell-update the Murnaghan-Tait and power-law steps were compute-bound at three times the Dowson-Higginson step time.
 // For the operands an equation of state sees (x > 0 a density ratio, |y ln x| far below 700) a plain exp(y ln x) is
 // accurate to a few 1e-16 |y ln x|: ln through the mantissa in [1/sqrt2, sqrt2) and the atanh series (11 terms), exp by
-// reduction with ln 2 and a degree-13 polynomial -- about 45 operations.  The host build (tests/hostcheck) keeps std::pow.
-GPF_HD double fast_log(double x) {
-#if defined(__HIP_DEVICE_COMPILE__)
+// reduction with ln 2 and a degree-13 polynomial -- about 45 operations.  The *_series forms are plain C++ (compiled for the
+// host too: tests/hostcheck compares them with std::log / std::exp / std::pow, special values included); the device code
+// calls them, the host statement of the closures keeps the C library.
+// Special values follow np.log / np.exp / np.power, because a state that blows up must END the run (q_is_valid,
+// problem.py:319-332) instead of carrying on with finite garbage: log(0) = -inf, log(x < 0) = NaN, exp(NaN) = NaN,
+// exp(t > 709.78) = inf, x^0 = 1, 0^y = 0 / inf for y > 0 / y < 0.  (A negative base gives NaN: np.power does the same for
+// the fractional exponents an equation of state has.)
+GPF_HD double fast_log_series(double x) {
     int e;
     double m = __builtin_frexp(x, &e);                      // m in [0.5, 1)
     const bool low = m < 0.70710678118654752;
@@ -145,15 +150,14 @@ GPF_HD double fast_log(double x) {
     p = fma(p, w, 1.0 / 5.0); p = fma(p, w, 1.0 / 3.0);
     const double lm = fma(z + z, p * w, z + z);             // ln m = 2 z (1 + w p)
     const double de = (double)e;
-    return fma(de, 0.69314718036912382, fma(de, 1.9082149292705877e-10, lm));      // e ln2 (hi + lo) + ln m
-#else
-    return log(x);
-#endif
+    double r = fma(de, 0.69314718036912382, fma(de, 1.9082149292705877e-10, lm));      // e ln2 (hi + lo) + ln m
+    r = x == __builtin_inf() ? x : r;
+    r = x == 0.0 ? -__builtin_inf() : r;
+    return x < 0.0 ? __builtin_nan("") : r;                 // (a NaN argument comes out of the series as NaN)
 }
 
-GPF_HD double fast_exp(double t) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const double tc = fmin(fmax(t, -745.0), 709.0);
+GPF_HD double fast_exp_series(double t) {
+    const double tc = fmin(fmax(t, -745.2), 709.8);         // (fmin / fmax drop a NaN: restored below)
     const double n = __builtin_rint(tc * 1.4426950408889634);
     double f = fma(n, -0.69314718036912382, tc);
     f = fma(n, -1.9082149292705877e-10, f);
@@ -162,19 +166,41 @@ GPF_HD double fast_exp(double t) {
     p = fma(p, f, 2.7557319223985893e-06); p = fma(p, f, 2.48015873015873e-05); p = fma(p, f, 1.984126984126984e-04);
     p = fma(p, f, 1.388888888888889e-03); p = fma(p, f, 8.333333333333333e-03); p = fma(p, f, 4.1666666666666664e-02);
     p = fma(p, f, 1.6666666666666666e-01); p = fma(p, f, 0.5); p = fma(p, f, 1.0); p = fma(p, f, 1.0);
-    return ldexp(p, (int)n);
+    // 2^n in two factors: n reaches -1075 and 1024, outside the exponents a single scale factor can hold
+    const int ni = (int)n, h1 = ni / 2;
+    double r = ldexp(ldexp(p, h1), ni - h1);
+    r = t > 709.782712893384 ? __builtin_inf() : r;
+    r = t < -745.13321910194122 ? 0.0 : r;
+    return t != t ? t : r;
+}
+
+GPF_HD double pow_pos_series(double x, double y) {
+    const double r = fast_exp_series(y * fast_log_series(x));       // x = 0: exp(-+inf) = 0 / inf
+    return y == 0.0 ? 1.0 : r;                                      // (0 * inf would be NaN)
+}
+
+GPF_HD double fast_log(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fast_log_series(x);
+#else
+    return log(x);
+#endif
+}
+
+GPF_HD double fast_exp(double t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fast_exp_series(t);
 #else
     return exp(t);
 #endif
 }
 
-// x^y for x > 0 (anything else: NaN, like np.power of a negative base with a fractional exponent)
+// x^y for x >= 0 (a negative base: NaN, like np.power with a fractional exponent)
 GPF_HD double pow_pos(double x, double y) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const double r = fast_exp(y * fast_log(x));
-    return x > 0.0 ? r : __builtin_nan("");
+    return pow_pos_series(x, y);
 #else
-    return pow(x, y);
+    return x < 0.0 ? __builtin_nan("") : pow(x, y);
 #endif
 }
 

@@ -27,7 +27,8 @@ inline FftLib& fftlib() {
     if (tried) return F;
     tried = true;
     void* hd = nullptr;
-    if (const char* path = getenv("GPF_HIPFFT_PATH")) hd = dlopen(path, RTLD_NOW | RTLD_GLOBAL);   // the copy PyTorch bundles
+    hd = dlopen("libhipfft.so.0", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);                         // an image already mapped wins (roclibs())
+    if (!hd) if (const char* path = getenv("GPF_HIPFFT_PATH")) hd = dlopen(path, RTLD_NOW | RTLD_GLOBAL);   // the copy PyTorch bundles
     if (!hd) hd = dlopen("libhipfft.so.0", RTLD_NOW | RTLD_GLOBAL);
     if (!hd) hd = dlopen("libhipfft.so", RTLD_NOW | RTLD_GLOBAL);
     if (!hd) hd = dlopen("/opt/rocm/lib/libhipfft.so", RTLD_NOW | RTLD_GLOBAL);

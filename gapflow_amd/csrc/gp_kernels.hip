@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <stdlib.h>
+#include <string>
 #include "device_types.hpp"
 
 namespace gpf {
@@ -601,6 +602,21 @@ __global__ void k_gp_identity(double* I, int n) {
     if (i < n) I[i + (long long)j * n] = i == j ? 1.0 : 0.0;
 }
 
+// B = A^T, n x n column-major (32 x 32 tiles through LDS; block 32 x 8)
+__global__ void k_gp_transpose(const double* __restrict__ A, double* __restrict__ B, int n) {
+    __shared__ double t[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int i = bx + threadIdx.x, j = by + r;
+        if (i < n && j < n) t[r][threadIdx.x] = A[i + (long long)j * n];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int i = by + threadIdx.x, j = bx + r;       // B(i, j) = A(j, i)
+        if (i < n && j < n) B[i + (long long)j * n] = t[threadIdx.x][r];
+    }
+}
+
 __global__ void k_gp_clean_lower(double* Lm, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
     if (i < n && i < j) Lm[i + (long long)j * n] = 0.0;
@@ -626,13 +642,31 @@ struct RocLibs {
 // rocBLAS enum values (rocblas-types.h): fill lower = 122, side left = 141, op none = 111, diag non-unit = 131
 enum { ROC_FILL_LOWER = 122, ROC_SIDE_LEFT = 141, ROC_SIDE_RIGHT = 142, ROC_OP_NONE = 111, ROC_OP_TRANS = 112, ROC_DIAG_NON_UNIT = 131 };
 
+// ONE rocBLAS / rocSOLVER image per process, and from ONE ROCm release.  A PyTorch-ROCm wheel bundles its own ROCm (HIP runtime,
+// rocBLAS, rocSOLVER, hipBLASLt, rocRoller ... with the system's SONAMEs); two rocBLAS images in one process crash in
+// rocRoller's static component registry when the second one is initialised, and a rocSOLVER of another release than the HIP
+// runtime / rocBLAS that serve the process stalled for minutes registering its code objects (profiles/r03_rocsolver/README.md:
+// the cause of the hang and of the abort recorded in round 2).  Therefore:
+//   * rocBLAS: the image ALREADY MAPPED wins (RTLD_NOLOAD by SONAME); only if there is none, GPF_ROCBLAS_PATH or the loader's
+//     default is opened;
+//   * rocSOLVER (GPF_USE_ROCSOLVER=1): an image already mapped, else the copy that lies NEXT TO the rocBLAS in use; never one
+//     found through the search path, which may belong to another release.
+inline std::string dir_of_symbol(void* sym) {
+    Dl_info info;
+    if (!sym || !dladdr(sym, &info) || !info.dli_fname) return "";
+    std::string f = info.dli_fname;
+    const size_t k = f.rfind('/');
+    return k == std::string::npos ? "" : f.substr(0, k);
+}
+
 inline RocLibs& roclibs() {
     static RocLibs R;
     static bool tried = false;
+    static std::string err_text;
     if (tried) return R;
     tried = true;
-    void* hb = nullptr;
-    if (const char* path = getenv("GPF_ROCBLAS_PATH")) hb = dlopen(path, RTLD_NOW | RTLD_GLOBAL);   // the copy PyTorch bundles
+    void* hb = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);         // whatever the process already uses
+    if (!hb) if (const char* path = getenv("GPF_ROCBLAS_PATH")) hb = dlopen(path, RTLD_NOW | RTLD_GLOBAL);     // the copy PyTorch bundles
     if (!hb) hb = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
     if (!hb) hb = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
     if (!hb) hb = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
@@ -646,14 +680,19 @@ inline RocLibs& roclibs() {
     if (!R.ok) { R.err = "rocBLAS symbols missing"; return R; }
     const char* use = getenv("GPF_USE_ROCSOLVER");
     if (use && use[0] == '1') {
-        void* hs = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
-        if (!hs) hs = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!hs) hs = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+        void* hs = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+        const std::string dir = dir_of_symbol((void*)R.create);
+        for (const char* name : {"/librocsolver.so.0", "/librocsolver.so"})
+            if (!hs && !dir.empty()) hs = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_GLOBAL);
         if (hs) {
             R.potrf = (RocLibs::potrf_t)dlsym(hs, "rocsolver_dpotrf");
             R.potrs = (RocLibs::potrs_t)dlsym(hs, "rocsolver_dpotrs");
         }
-        if (!R.potrf || !R.potrs) { R.ok = false; R.err = "GPF_USE_ROCSOLVER=1 but rocSOLVER could not be loaded"; }
+        if (!R.potrf || !R.potrs) {
+            R.ok = false;
+            err_text = "GPF_USE_ROCSOLVER=1 but no rocSOLVER lies next to the rocBLAS in use (" + dir + "): a copy of another ROCm release is not loaded";
+            R.err = err_text.c_str();
+        }
     }
     return R;
 }

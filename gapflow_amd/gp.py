@@ -371,6 +371,9 @@ class Surrogate:
         self._step, self._pause, self.last_fit_train_size = 0, 0, 0
         self.optimise = True            # False: keep the initial hyper-parameters (timing runs, conditioning tests)
         self.theta = None
+        self.params_init = None
+        self.events = []                # ('train', step, reason, database size) / ('add', step, raw feature row): what the loop decided
+        self._attached_scales = None    # (X_scale of the active dimensions, Yscale) the device model currently uses
         self.maximum_variance = np.inf
         self.variance_tol = 0.0
         self._var_valid = False
@@ -414,17 +417,24 @@ class Surrogate:
     kernel_lengthscale = property(lambda self: np.exp(-self.theta[1:]))      # tinygp Linear scale = exp(-log_scale)
     trusted = property(lambda self: self.maximum_variance < self.variance_tol)
 
+    _say = staticmethod(print)          # the training / active-learning report (gp.py:296-300, 498-503)
+
     # -- train / attach ------------------------------------------------------------------------
     def train(self, reason=0, optimise=None):
         """gp.py:290-335.  optimise=False keeps theta (used by benchmarks with fixed hyper-parameters)."""
         self.last_fit_train_size = self.database.size
-        print('#' + 17 * '-' + f"GP TRAINING ({self.name.upper()})" + 17 * '-')
-        print('# Timestep     :', self._step)
-        print('# Reason       :', ['DB', 'AL'][reason])
-        print('# Database size:', self.database.size)
+        self.events.append(('train', self._step, reason, self.database.size))
+        say = self._say
+        say('#' + 17 * '-' + f"GP TRAINING ({self.name.upper()})" + 17 * '-')
+        say('# Timestep     :', self._step)
+        say('# Reason       :', ['DB', 'AL'][reason])
+        say('# Database size:', self.database.size)
         optimise = self.optimise if optimise is None else optimise
         X, Y, sigma = self.Xtrain, self.Ytrain, self.Yerr
-        theta0 = np.concatenate([[0.0], np.log(np.std(X, axis=0))])         # stress.py:281-284, 592-595
+        if self.params_init is None:
+            # set ONCE, by init() (stress.py:281-284, 592-595): every later fit starts from the first training set's values
+            self.params_init = np.concatenate([[0.0], np.log(np.std(X, axis=0))])
+        theta0 = self.params_init
         if optimise or self.theta is None:
             if optimise:
                 # objective and gradient on the device (GPF_GP_TRAIN=host: the NumPy / LAPACK statement of the same arithmetic)
@@ -447,12 +457,12 @@ class Surrogate:
                 self.theta, obj = res.x, res.fun
             else:
                 self.theta, obj = theta0, neg_log_likelihood(theta0, X, Y, sigma)[0]
-            print(f'# Objective    : {obj:.5g}')
+            say(f'# Objective    : {obj:.5g}')
         self.attach()
         if self._step > 0:
             self.write()
         if reason == 0:
-            print('#' + 50 * '-')
+            say('#' + 50 * '-')
 
     def attach(self):
         """Factorise K on the device with the current data and hyper-parameters (gp.py:323)."""
@@ -466,6 +476,30 @@ class Surrogate:
                                            _lib.as_dp(inv_scale), float(self.Yerr), float(self.Yscale)))
         p._closures_stale = True
         self._var_valid = False
+        self._attached_scales = (np.array(xs), float(self.Yscale))
+
+    def sync_scales(self):
+        """The reference normalises test inputs and outputs with the database's CURRENT scales (the Xtest / Yscale
+        properties, stress.py:195-242, 542-564) whatever the age of the fitted model: when another surrogate has added a point
+        that moved a maximum, this model -- not refitted before the next predictor stage -- goes on with its old
+        factorisation and the new scales.  Returns True if the device model's scales changed."""
+        if self._attached_scales is None:
+            return False
+        xs, ys = _lib.f64c(self.database.X_scale[self.active_dims]), float(self.Yscale)
+        if np.array_equal(xs, self._attached_scales[0]) and ys == self._attached_scales[1]:
+            return False
+        p = self._p
+        _lib.check(p._lib.gpf_gp_set_scales(p._h, self.which, _lib.as_dp(xs), ys))
+        self._attached_scales = (np.array(xs), ys)
+        p._closures_stale = True
+        self._var_valid = False
+        return True
+
+    def init(self):
+        """stress.py:278-287, 586-598: first fit, then one inference WITH the variance (gp.py:390-414): maximum_variance and
+        variance_tol exist from here on."""
+        self.train(reason=0)
+        self.compute_variance(on_open_step=False)
 
     def write(self):
         h = self.history
@@ -533,19 +567,21 @@ class Surrogate:
             before = self.maximum_variance / self.variance_tol
             while not self.trusted and counter < self.max_steps:
                 counter += 1
-                self.database.add_data(self._most_uncertain(features_of_cell)[None, :])
+                Xnew = self._most_uncertain(features_of_cell)
+                self.events.append(('add', self._step, np.array(Xnew, float)))
+                self.database.add_data(Xnew[None, :])
                 tic = datetime.now()
                 self.train(reason=1)
                 self.cumtime_train += datetime.now() - tic
                 changed = True
                 self.compute_variance(on_open_step=True)
                 after = self.maximum_variance / self.variance_tol
-                print(f"# AL {counter:2d}/{self.max_steps:2d}     : {before:.3f} --> {after:.3f}")
-                print('#' + 50 * '-')
+                self._say(f"# AL {counter:2d}/{self.max_steps:2d}     : {before:.3f} --> {after:.3f}")
+                self._say('#' + 50 * '-')
             if counter == self.max_steps:
-                print("# Active learning loop missed uncertainty threshold")
-                print(f"# Pause for {self.pause_steps} steps...")
-                print('#' + 50 * '-')
+                self._say("# Active learning loop missed uncertainty threshold")
+                self._say(f"# Pause for {self.pause_steps} steps...")
+                self._say('#' + 50 * '-')
                 self._pause = self.pause_steps
         return changed
 
@@ -567,11 +603,9 @@ class SlabSurrogate(Surrogate):
     every rank (same data, same deterministic host optimiser); only the two domain-wide decisions of active
     learning -- the largest variance and the cell it belongs to -- are exchanged."""
 
-    def train(self, reason=0, optimise=None):
-        if self._p.rank == 0:
-            return super().train(reason, optimise)
-        with contextlib.redirect_stdout(_io.StringIO()):        # one training report per job, not per rank
-            return super().train(reason, optimise)
+    def _say(self, *a, **k):
+        if self._p.rank == 0:           # one training report per job, not per rank
+            print(*a, **k)
 
     def compute_variance(self, on_open_step):
         super().compute_variance(on_open_step)

@@ -249,7 +249,9 @@ class Problem:
         """The device field has moved on: the host mirror is stale until `q` is read again.  In the reference `q` is the
         live field, so `q = p.q; p.update(); q[0] *= 1.01` edits the NEW state; here that array still holds the old one
         and the edit could only be dropped or misapplied.  The stale mirror is therefore made read-only -- such an edit
-        raises at once -- and becomes writable (and current) again with the next read of `p.q`."""
+        raises at once -- and the next read of `p.q` hands out a NEW array holding the current state.  (NumPy views keep the
+        flag they were created with: a view taken earlier, `rho = p.q[0]`, stays writable, but it aliases the retired array
+        and can no longer reach the mirror in use; an edit through it goes nowhere, like an edit of any copy.)"""
         self._device_newer = True
         self._closures_stale = True
         self._q_host.flags.writeable = False
@@ -258,7 +260,7 @@ class Problem:
     def q(self):
         """Full density field (3, Nx+2, Ny+2): rho, jx, jy -- a writable host mirror."""
         if self._device_newer:
-            self._q_host.flags.writeable = True
+            self._q_host = np.empty_like(self._q_host)      # the retired array stays read-only; its old views cannot alias this one
             _lib.check(self._lib.gpf_download(self._h, _lib.FIELD_Q, _lib.as_dp(self._q_host), self._q_host.size))
             self._q_snapshot = self._q_host.copy()
             self._device_newer = False
@@ -342,7 +344,7 @@ class Problem:
             # init_database + init of every surrogate (problem.py:418-424, stress.py:278-287, 586-598)
             self.database.initialize(self._features(), self.grid['dim'])
             for m in self._gp_models.values():
-                m.train(reason=0)
+                m.init()
         _lib.check(self._lib.gpf_pre_run(self._h))
         if self._kinetic_energy_old is not None:
             _lib.check(self._lib.gpf_set_ekin_old(self._h, float(self._kinetic_energy_old)))
@@ -408,6 +410,8 @@ class Problem:
 
         _lib.check(lib.gpf_open_step(h))
         for i in range(2):
+            for m in self._gp_models.values():
+                m.sync_scales()             # the database may have grown through another model since this one was fitted
             _lib.check(lib.gpf_stage_closures(h))
             changed = False
             for name in ('zz', 'xz', 'yz'):
@@ -417,6 +421,8 @@ class Problem:
             if changed:
                 _lib.check(lib.gpf_stage_closures(h))
             _lib.check(lib.gpf_stage_advance(h, i))
+        for m in self._gp_models.values():
+            m.sync_scales()                 # the sound speed that closes the step sees the current scales too
         sc = _lib.GpfScalars()
         _lib.check(lib.gpf_close_step(h, C.byref(sc)))
         if sc.invalid:

@@ -557,7 +557,7 @@ class SlabProblem:
         if self._gp_models:
             self.database.initialize(self._features_global, self.grid['dim'])       # identical on every rank
             for m in self._gp_models.values():
-                m.train(reason=0)
+                m.init()
         _lib.check(self.lib.gpf_pre_run(self._h))
         g = self.global_scalars()
         num, grid = self.input['numerics'], self.input['grid']
@@ -592,6 +592,8 @@ class SlabProblem:
 
         _lib.check(lib.gpf_open_step(h))
         for i in range(2):
+            for m in self._gp_models.values():
+                m.sync_scales()
             _lib.check(lib.gpf_stage_closures(h))
             changed = False
             for name in ('zz', 'xz', 'yz'):
@@ -604,6 +606,8 @@ class SlabProblem:
             _lib.check(lib.gpf_stage_message(h))
             self.dist.all_gather_into_tensor(d.gathered, d.message)
             _lib.check(lib.gpf_stage_absorb(h, gathered, self.world, d.rank_lo, d.rank_hi))
+        for m in self._gp_models.values():
+            m.sync_scales()
         _lib.check(lib.gpf_close_step_local(h))
         self.dist.all_gather_into_tensor(d.gathered, d.message)
         sc = _lib.GpfScalars()

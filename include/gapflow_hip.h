@@ -273,6 +273,13 @@ int gpf_gp_set_model(gpf_handle* h, int which, int n, int d, int m, const int32_
                      const double* Xn, const double* Yn, double amp, const double* inv_scale, double sigma,
                      double yscale);
 int gpf_gp_clear_model(gpf_handle* h, int which);
+/* The reference normalises test inputs and outputs with the database's CURRENT max-abs scales (properties Xtest / Yscale,
+ * stress.py:195-242, 542-564) while the factorised model and its cached alpha are those of the last fit (gp.py:343-349):
+ * after the database has grown through another model and before this model's next fit, the mean is
+ * Ks(x / x_scale_now)^T alpha_fit * yscale_now and the variance alike; the GP sound speed re-solves alpha from
+ * Y_raw / yscale_now (stress.py:588, 533-535), so there only x_scale changes.  This call hands the current scales to an
+ * attached model without refitting it. */
+int gpf_gp_set_scales(gpf_handle* h, int which, const double* x_scale, double yscale);
 /* Predictive variance A - ||L^-1 k(X, x*)||^2 (gp.py:509-522) of model `which` at every cell, written to
  * the GPF_FIELD_*_VAR field (times yscale^2); *max_var = its maximum (the active-learning criterion,
  * gp.py:408).  on_open_step != 0: evaluate on the working field of an open step. */

@@ -168,3 +168,223 @@ class OracleSurrogate:
     def v_sound(self, problem):
         g = self.fit.dmean_dx0(self.xtest(problem))
         return np.sqrt(g.max() * self.Yscale / self.X_scale[0])
+
+
+# ---------------------------------------------------------------------------------------------
+# Active learning: the surrogate's train / infer / add-a-point loop, the database it
+# extends and the Mock MD runner that answers.  PARITY UNPINNED like the rest of this file (the reference
+# holds no numeric fixture of an active-learning run); what IS restated line by line is the control flow.
+#
+#   GaPFlow/models/gp.py:290-335    _train: _last_fit_train_size = database.size, optimise from params_init
+#                                   (set ONCE, in init(): stress.py:281-284, 592-595), _cache = None
+#   gp.py:390-414                   _infer: with compute_var the variance field, its maximum and
+#                                   variance_tol = max(atol Yerr Yscale, rtol Yscale)^2; otherwise the mean alone and the
+#                                   variance field of an EARLIER evaluation stays
+#   gp.py:419-430                   _active_learning: imax = argmax(var) over all cells incl. ghosts (first hit),
+#                                   database.add_data(_Xtest[imax])
+#   gp.py:435-506                   predict: predictor stage only: _step += 1, _pause = max(-1, _pause - 1), retrain when
+#                                   the database has grown; variance only if compute_var AND predictor; the loop
+#                                   `while not trusted and counter < max_steps`; _pause = pause_steps when it ran out
+#   stress.py:353-354, 617-618      compute_var handed to predict = use_active_learning or compute_var
+#   problem.py:530                  compute_var = one step before an output step
+#   db.py:264-266, 278-369          max-abs normalisers recomputed after every added point; initialize(); add_data()
+#   md/mock.py:81-107               Mock run = fixed-form laws + three fixed normal draws
+#
+# Quirks kept because the product has to match them:
+#   * Xtrain is normalised by the database's CURRENT X_scale and the test inputs likewise, Yscale is the CURRENT one
+#     (properties, stress.py:195-258, 542-569), while the factorised model and the cached alpha (gp.py:343-349) are those
+#     of the last fit.  Between a growth of the database by ANOTHER model and this model's next fit (one corrector stage)
+#     the mean is therefore Ks(X* / X_scale_now)^T alpha_fit * Yscale_now.
+#   * the GP sound speed goes through gp.predict(self.Ytrain, x) (stress.py:588, 533-535), i.e. a fresh
+#     alpha = K_fit^-1 (Y_raw / Yscale_now): times Yscale_now the output scale cancels, the input scale does not.
+# Deviation shared with the product: jax's PRNG streams -> NumPy default_rng with the same seeds.
+# ---------------------------------------------------------------------------------------------
+class OracleMock:
+    def __init__(self, prop, geo, gp):
+        self.noise = (gp['press']['obs_stddev'] if gp['press_gp'] else 0., gp['shear']['obs_stddev'] if gp['shear_gp'] else 0.)
+        self.prop, self.geo = prop, geo
+
+    def run(self, X):
+        from . import closures as cl
+        X = np.asarray(X, float)
+        n = np.random.default_rng(123).standard_normal(3) * np.array([self.noise[0], self.noise[1], self.noise[1]])
+        q, h = X[:3, None], X[3:6, None]
+        U, V, eta, zeta = self.geo['U'], self.geo['V'], self.prop['shear'], self.prop['bulk']
+        bot = cl.stress_bottom(q, h, U, V, eta, zeta, X[6:7])[:, 0] + n[1]
+        top = cl.stress_top(q, h, U, V, eta, zeta, X[6:7])[:, 0] + n[2]
+        p = cl.eos_pressure(X[0:1], self.prop)[0] + n[0]
+        s = self.noise[1]
+        return np.concatenate([[p], bot, top]), np.array([self.noise[0], 0., 0., 0., s, s, 0., 0., 0., 0., s, s, 0.])
+
+
+class OracleDatabase:
+    def __init__(self, md, db, num_features=7):
+        self._md, self._db = md, db
+        self._Xtrain, self._Ytrain, self._Ytrain_err = np.empty((0, num_features)), np.empty((0, 13)), np.empty((0, 13))
+        self.X_scale, self.Y_scale = np.ones(num_features), np.ones(13)
+        self.added = []                 # (raw feature row) of every point added after initialize(), in order
+
+    size = property(lambda self: self._Xtrain.shape[0])
+    Xtrain = property(lambda self: self._Xtrain / self.X_scale)
+    Ytrain_err = property(lambda self: self._Ytrain_err / self.Y_scale)
+
+    @staticmethod
+    def _normalizer(x):
+        return np.maximum(np.max(np.abs(x), axis=0), 1e-12)
+
+    def add_data(self, Xnew, record=True):
+        for X in np.atleast_2d(Xnew):
+            Y, Ye = self._md.run(X)
+            self._Xtrain = np.vstack([self._Xtrain, X])
+            self._Ytrain = np.vstack([self._Ytrain, Y])
+            self._Ytrain_err = np.vstack([self._Ytrain_err, Ye])
+            self.X_scale, self.Y_scale = self._normalizer(self._Xtrain), self._normalizer(self._Ytrain)
+            if record:
+                self.added.append(np.array(X, float))
+
+    def initialize(self, Xtest, dim):
+        from scipy.stats import qmc
+        db = self._db
+        nsample = db['init_size'] - self.size
+        if nsample <= 0:
+            return
+        mean = lambda k: float(Xtest[0, k]) if (Xtest[:, k] == Xtest[0, k]).all() else float(np.mean(Xtest[:, k]))
+        if dim == 1:
+            flux, active = mean(1), [0, 1]
+        else:
+            flux, active = np.hypot(mean(1), mean(2)), [0, 1, 2]
+        rho, w = mean(0), db['init_width']
+        lo = np.array([(1.0 - w) * rho, 0.5 * flux, -0.5 * flux])[active]
+        hi = np.array([(1.0 + w) * rho, 1.5 * flux, 0.5 * flux])[active]
+        rng = np.random.default_rng(db['init_seed'])
+        if db['init_method'] == 'rand':
+            samples = rng.uniform(lo, hi, size=(nsample, len(active)))
+        elif db['init_method'] == 'lhc':
+            samples = qmc.scale(qmc.LatinHypercube(d=len(active), seed=rng).random(n=nsample), lo, hi)
+        else:
+            samples = qmc.scale(qmc.Sobol(d=len(active), seed=rng).random_base2(m=int(np.ceil(np.log2(nsample)))), lo, hi)
+            nsample = samples.shape[0]
+        choice = rng.choice(Xtest.shape[0], size=nsample, replace=False)
+        if len(active) == 2:
+            samples = np.hstack([samples, np.zeros((nsample, 1))])
+        self.add_data(np.column_stack([samples, Xtest[choice, 3:]]), record=False)
+
+
+class OracleGP:
+    """GaussianProcessSurrogate + the Pressure / WallStress properties for one closure; same interface towards
+    OracleProblem as OracleSurrogate.  `events` lists what happened, for the parity test:
+    ('train', step, reason, database size), ('add', step, cell index, raw features)."""
+
+    def __init__(self, kind, cfg, database, optimise=True):
+        self.kind, self.database, self.optimise = kind, database, optimise
+        if kind == 'press':
+            self.dims, self.cols = list(cfg.get('active_dims', [0, 3])), [0]
+        else:
+            oi = 4 if kind == 'shear_x' else 3
+            key, default = ('active_dims_x', [0, 1, 3]) if kind == 'shear_x' else ('active_dims_y', [0, 2, 3])
+            self.dims, self.cols = list(cfg.get(key, default)), [oi + 1, oi + 7]
+        self.atol, self.rtol = cfg['atol'], cfg['rtol']
+        self.max_steps, self.pause_steps, self.use_active_learning = cfg['max_steps'], cfg['pause_steps'], cfg['active_learning']
+        self._step, self._pause, self.last_fit_train_size = 0, 0, 0
+        self.variance = None            # the stored variance field (raw units), possibly of an earlier state
+        self.maximum_variance, self.variance_tol = None, None
+        self.events = []
+        self.fit = None
+
+    # -- stress.py:195-258, 542-569 ----------------------------------------------------------------
+    @property
+    def Xtrain(self):
+        return self.database.Xtrain[:, self.dims]          # all rows: equal to [:last_fit_train_size] whenever it is used to fit
+
+    @property
+    def Yscale(self):
+        return self.database.Y_scale[0] if self.kind == 'press' else np.max(self.database.Y_scale[self.cols])
+
+    @property
+    def Ytrain(self):
+        return self.database._Ytrain[:self.last_fit_train_size][:, self.cols] / self.Yscale
+
+    @property
+    def Yerr(self):
+        n = self.last_fit_train_size
+        if self.kind == 'press':
+            return float(np.mean(self.database.Ytrain_err[:n, 0]))
+        return float(np.mean(self.database._Ytrain_err[:n][:, self.cols] / self.Yscale))
+
+    trusted = property(lambda self: self.maximum_variance < self.variance_tol)
+
+    def xtest(self, problem):
+        return (features(problem.q, problem.topo, problem.extra) / self.database.X_scale)[:, self.dims]
+
+    # -- gp.py:290-335 -------------------------------------------------------------------------------
+    def _train(self, reason):
+        self.last_fit_train_size = self.database.size
+        X, Y, sigma = self.Xtrain, self.Ytrain, self.Yerr
+        self.theta = train(X, Y, sigma, self.params_init)[0] if self.optimise else np.array(self.params_init)
+        self.fit = Fit(X, Y, np.exp(self.theta[0]), np.exp(-self.theta[1:]), sigma)
+        self.Yscale_fit = self.Yscale
+        self.events.append(('train', self._step, reason, self.database.size))
+
+    def init(self, problem):
+        # Problem._pre_run: init_database (problem.py:418-420) then init (stress.py:278-287, 586-598)
+        self.database.initialize(features(problem.q, problem.topo, problem.extra), problem.grid['dim'])
+        self.params_init = np.concatenate([[0.0], np.log(np.std(self.Xtrain, axis=0))])
+        self._train(0)
+        self._infer(problem, True)
+
+    # -- gp.py:337-414 -------------------------------------------------------------------------------
+    def _infer(self, problem, compute_var):
+        Xs = self.xtest(problem)
+        shape = problem.q.shape[1:]
+        if compute_var:
+            m, v = self.fit.mean_var(Xs)
+            self.variance = v.reshape(shape) * self.Yscale**2
+            self.maximum_variance = self.variance.max()
+            self.variance_tol = max(self.atol * self.Yerr * self.Yscale, self.rtol * self.Yscale)**2
+        else:
+            m = self.fit.mean(Xs)
+        return (m * self.Yscale).T.reshape((-1,) + shape)
+
+    # -- gp.py:419-506 -------------------------------------------------------------------------------
+    def predict(self, problem, predictor=False, compute_var=False):
+        compute_var = self.use_active_learning or compute_var              # stress.py:353-354, 617-618
+        if predictor:
+            self._step += 1
+            self._pause = max(-1, self._pause - 1)
+            if self.last_fit_train_size < self.database.size:
+                self._train(0)
+        m = self._infer(problem, compute_var and predictor)
+        if self.use_active_learning and predictor and self._pause < 0:
+            counter = 0
+            while not self.trusted and counter < self.max_steps:
+                counter += 1
+                imax = int(np.argmax(self.variance))                        # first hit, all cells incl. ghosts
+                Xnew = features(problem.q, problem.topo, problem.extra)[imax]
+                self.events.append(('add', self._step, imax, Xnew.copy()))
+                self.database.add_data(Xnew[None, :])
+                self._train(1)
+                m = self._infer(problem, True)
+            if counter == self.max_steps:
+                self._pause = self.pause_steps
+        return m[0] if self.kind == 'press' else (m[0], m[1])
+
+    def v_sound(self, problem):
+        # stress.py:533-535 with self.eos = gp.predict(self.Ytrain, .): alpha = K_fit^-1 (Y_raw / Yscale_now)
+        g = self.fit.dmean_dx0(self.xtest(problem)) * (self.Yscale_fit / self.Yscale)
+        return np.sqrt(g.max() * self.Yscale / self.database.X_scale[0])
+
+
+def attach(problem, input_dict, optimise=True):
+    """Problem.__init__ / _select_gp_config (problem.py:223-249, 643-660) for the oracle: a Mock-backed database and
+    press + shear-x (+ shear-y in 2-D) surrogates, plugged into `problem.gp_models`."""
+    gp, db = input_dict['gp'], input_dict['db']
+    database = OracleDatabase(OracleMock(input_dict['properties'], input_dict['geometry'], gp), db)
+    models = {}
+    if gp.get('press') is not None:
+        models['press'] = OracleGP('press', gp['press'], database, optimise)
+    if gp.get('shear') is not None:
+        models['shear_x'] = OracleGP('shear_x', gp['shear'], database, optimise)
+        if problem.grid['dim'] == 2:
+            models['shear_y'] = OracleGP('shear_y', gp['shear'], database, optimise)
+    problem.gp_models = models
+    return database, models

@@ -28,24 +28,27 @@ properties: {shear: 0.0794, bulk: 0., EOS: DH, P0: 101325., rho0: 877.7007, C1: 
 """
 
 
-def test_cfg2_on_eight_slabs_is_bitwise_the_undivided_run(hiplib):
-    """bench.py's workload cut into 8 x-slabs of 512 rows, 10 steps (both sweep orders of MC_order 0): every rank's owned
+@pytest.mark.parametrize('mc_order', [1, 0], ids=['bench-workload', 'alternating-sweeps'])
+def test_cfg2_on_eight_slabs_is_bitwise_the_undivided_run(hiplib, mc_order):
+    """bench.py's workload (MC_order 1, its default) cut into 8 x-slabs of 512 rows, 10 steps, and the same with the sweep
+    order alternating from step to step (MC_order 0: both predictor directions of the kernel): every rank's owned
     rows AND its two outer rows are bit for bit the undivided handle's, dt is the same number on every rank; the kinetic
     energy is summed over another partition (1e-12)."""
     import torch
     from gapflow_amd import Problem
     from gapflow_amd.slab import SlabProblem, ThreadWorld, HALO_SEAM, HALO_NEIGHBOUR
     nsteps = 10
+    text = JOURNAL_4096.replace('max_it: 100000000', f'max_it: 100000000, MC_order: {mc_order}')
 
     def rank_body(group):
-        slab = SlabProblem.from_string(JOURNAL_4096, device=0, dist=group)
+        slab = SlabProblem.from_string(text, device=0, dist=group)
         slab.pre_run()
         slab.advance(nsteps)
         st = slab.state()
         return slab.layout, slab.local_q(), st
 
     runs = ThreadWorld(WORLD, torch).run(rank_body)
-    serial = Problem.from_string(JOURNAL_4096)
+    serial = Problem.from_string(text)
     serial._pre_run()
     serial._advance(nsteps, honor_stop=False)
     ref = serial.q

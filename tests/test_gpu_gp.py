@@ -226,6 +226,52 @@ def test_device_likelihood_matches_the_host_statement(hiplib, n, d, m):
         assert dev(bad)[0] == 1e300 == host(bad)[0]
 
 
+def test_device_gradient_at_a_trained_ill_conditioned_theta(hiplib):
+    """The likelihood gradient where training ends up: amplitude e^2 over a noise of 1e-5 of its square root and
+    length scales of ten domain widths, cond(K) ~ 5e10.  Truth = the same formula in 40-digit arithmetic (mpmath, n = 48);
+    the device gradient (K^-1 = Y Y^T with Y = L^-T by substitution, gp_inverse_transposed) must be as close to it as the
+    LAPACK statement on the host (dpotrf / dpotri) is, up to a factor of 10."""
+    import mpmath as mp
+    from gapflow_amd.gp import NegLogLikelihood, DeviceNegLogLikelihood
+    rng = np.random.default_rng(3)
+    n, d, m = 48, 2, 1
+    X = rng.uniform(-1., 1., (n, d))
+    Y = (np.sin(2 * X[:, 0]) * (1 + 0.3 * X[:, 1]))[:, None]
+    theta = np.array([2.0, 3.0, 3.4])
+    sigma = 1e-5 * np.exp(theta[0] / 2)
+    # --- 40 digits ---
+    mp.mp.dps = 40
+    amp, s = mp.e**mp.mpf(float(theta[0])), [mp.e**(-mp.mpf(float(t))) for t in theta[1:]]
+    sq3 = mp.sqrt(3)
+    Kf = mp.matrix(n, n)
+    dK = [mp.matrix(n, n) for _ in range(d)]
+    for i in range(n):
+        for j in range(n):
+            sd = [s[k] * (mp.mpf(float(X[i, k])) - mp.mpf(float(X[j, k]))) for k in range(d)]
+            r = mp.sqrt(sum(v * v for v in sd))
+            E = mp.e**(-sq3 * r)
+            Kf[i, j] = amp * (1 + sq3 * r) * E
+            for k in range(d):
+                dK[k][i, j] = 3 * amp * E * sd[k]**2
+    K = Kf.copy()
+    for i in range(n):
+        K[i, i] += mp.mpf(float(sigma))**2
+    Kinv = K**-1
+    y = mp.matrix([mp.mpf(float(v)) for v in Y[:, 0]])
+    alpha = Kinv * y
+    W = alpha * alpha.T - m * Kinv
+    truth = np.array([float(-mp.mpf(1) / 2 * sum(W[i, j] * G[i, j] for i in range(n) for j in range(n))) for G in [Kf] + dK])
+    cond = float(mp.norm(K, 'inf') * mp.norm(Kinv, 'inf'))
+    assert cond > 1e9, cond
+    gh = NegLogLikelihood(X, Y, sigma)(theta)[1]
+    with DeviceNegLogLikelihood(X, Y, sigma) as dev:
+        fd, gd = dev(theta)
+    assert fd < 1e300, 'the device factorisation must succeed at this theta'
+    eh, ed = np.abs(gh - truth), np.abs(gd - truth)
+    print(f'\n[likelihood gradient, cond(K) = {cond:.1e}] truth {truth}; |host - truth| {eh}; |device - truth| {ed}')
+    assert (ed <= 10 * eh + 1e-9 * np.abs(truth).max()).all(), (ed, eh)
+
+
 def test_training_on_the_device_finds_the_host_optimum(hiplib, monkeypatch):
     """Surrogate.train with the objective on the device (default) and with GPF_GP_TRAIN=host: BFGS from the same start ends
     at the same objective value (1e-6 of it).  The hyper-parameters themselves agree only where the likelihood determines

@@ -20,7 +20,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'gapflow_amd', 'csrc')
 VARIANTS = ['0, false, false, 1, 0', '0, false, false, -1, 0', '0, false, false, 1, 1', '0, false, false, -1, 1', '0, false, false, 1, 2',
             '0, false, false, 1, 3', '0, false, false, -1, 3', '2, false, false, 1, 3', '5, false, false, -1, 3', '0, true, false, 1, 0',
-            '0, false, true, 1, 0', '5, true, true, -1, 0']
+            '0, false, true, 1, 0', '5, true, true, -1, 0',
+            # the equations of state that go through pow / exp / log (one wave per SIMD, fewer rows ahead: Step2Weight) -- their
+            # closures decide the register allocation, so each heavy law is audited, one of them on the planes kernel
+            '1, false, false, 1, 3', '3, false, false, 1, 0', '3, false, false, -1, 3', '6, false, false, -1, 1']
 
 
 def regs_of(tok):
