@@ -106,9 +106,14 @@ def cpu_baseline(sample_n=2048, steps=10):
                       f"{os.cpu_count()} cores), same YAML at {sample_n}x{sample_n}, {steps} steps, {dt:.1f} s"}
 
 
+REPEATS = int(os.environ.get('GPF_BENCH_REPEATS', 5))
+
+
 def time_problem(text, steps, warmup):
-    """(wall seconds of `steps` steps, k_step ms per launch, all kernels ms per step) for one YAML input."""
+    """(wall seconds of `steps` steps: the median of REPEATS timed regions, k_step ms per launch, all kernels ms per step,
+    the walls of all repeats) for one YAML input."""
     import ctypes as C
+    import statistics
     from gapflow_amd import Problem, _lib
     with contextlib.redirect_stdout(sys.stderr):
         prob = Problem.from_string(text)
@@ -116,17 +121,21 @@ def time_problem(text, steps, warmup):
         lib = prob._lib
         if warmup > 0:
             prob._advance(warmup, honor_stop=False)
-        # --- timed region: K steps enqueued back to back, one host sync at the end ---
+        # --- timed region: EXACTLY K steps enqueued back to back, one host sync at the end; repeated REPEATS times on the running
+        #     problem (the boxes of the pool and the clocks within a call vary: one region of a few ms is one sample) ---
         nexec = C.c_int64(0)
-        _lib.check(lib.gpf_scalars(prob._h, C.byref(_lib.GpfScalars())))      # drains the stream
-        t0 = time.perf_counter()
-        done = 0
-        while done < steps:
-            n = min(4096, steps - done)
-            _lib.check(lib.gpf_step(prob._h, n, 0, None, 0, C.byref(nexec)))    # returns after a stream sync
-            done += n
-        t1 = time.perf_counter()
-        assert int(nexec.value) == warmup + steps, "steps were skipped inside the timed region"
+        walls = []
+        for rep in range(max(1, REPEATS)):
+            _lib.check(lib.gpf_scalars(prob._h, C.byref(_lib.GpfScalars())))      # drains the stream
+            t0 = time.perf_counter()
+            done = 0
+            while done < steps:
+                n = min(4096, steps - done)
+                _lib.check(lib.gpf_step(prob._h, n, 0, None, 0, C.byref(nexec)))    # returns after a stream sync
+                done += n
+            walls.append(time.perf_counter() - t0)
+            assert int(nexec.value) == warmup + (rep + 1) * steps, "steps were skipped inside the timed region"
+        t0, t1 = 0.0, statistics.median(walls)
         # --- kernel time of the dominant kernel, HIP events on the launch stream ---
         kt, tt = C.c_double(0), C.c_double(0)
         nk = min(max(steps, 1), 200)
@@ -134,7 +143,7 @@ def time_problem(text, steps, warmup):
         sc = prob._scalars()
         assert sc.invalid == 0 and sc.ekin == sc.ekin, "state went invalid during the benchmark"
         del prob
-    return t1 - t0, kt.value / nk, tt.value / nk
+    return t1 - t0, kt.value / nk, tt.value / nk, walls
 
 
 def stream_ceiling(planes_in, planes_out, cells):
@@ -163,8 +172,13 @@ def roofline(kernel_ms, cells, bytes_per_cell, traffic_kind, kernel):
 
 
 def run_single(args):
-    wall, kernel_ms, all_ms = time_problem(WORKLOAD_YAML.format(N=N_GRID), args.steps, args.warmup)
+    wall, kernel_ms, all_ms, walls = time_problem(WORKLOAD_YAML.format(N=N_GRID), args.steps, args.warmup)
     cells = N_GRID * N_GRID
+
+    def spread(ws):
+        ms = sorted(w / args.steps * 1e3 for w in ws)
+        return {"repeats": len(ms), "ms_per_step_min": ms[0], "ms_per_step_median": ms[len(ms) // 2], "ms_per_step_max": ms[-1],
+                "note": f"{len(ms)} timed regions of exactly {args.steps} steps each on the running problem; value / ms_per_step are the median's"}
     # The journal-bearing gap varies along x only: the kernel reads its topography as one (h, hx, hy) triple per row
     # (GPF_TOPO_PLANES=1 disables this), so of SURVEY.md 8(d)'s 72 B per cell-update only 48 B (q read + q write) are
     # compulsory HBM traffic for THIS workload.  `frac` is priced against those 48 B; the 72-B figure of the survey is
@@ -181,7 +195,7 @@ def run_single(args):
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"2D journal bearing {N_GRID}x{N_GRID}, fixed DH EOS, all-periodic, adaptive CFL 0.5 "
                                "(BASELINE.json configs[2])", "slabs": 1},
-        "roofline": roof,
+        "roofline": roof, "spread": spread(walls),
     }
     if not args.no_variants:
         # the journal gap is y-invariant, so also time a gap that varies in both directions with a
@@ -189,15 +203,17 @@ def run_single(args):
         text = WORKLOAD_YAML.format(N=N_GRID).replace("type: journal\n    CR: 1.e-2\n    eps: 0.7\n    U: 0.1\n    V: 0.",
                                                       "type: asperity\n    hmin: 2.e-6\n    hmax: 1.e-5\n    num: 1\n    U: 0.1\n    V: 0.05")
         assert 'asperity' in text
-        w2, k2, a2 = time_problem(text, args.steps, args.warmup)
+        w2, k2, a2, walls2 = time_problem(text, args.steps, args.warmup)
         r2 = roofline(k2, cells, BYTES_PER_CELL, 'planes', "k_step2<DH, topography planes>")
         r2["all_kernels_ms_per_step"] = a2
         out["variants"] = {"asperity_gap_2d_V0.05": {
             "workload": f"as the headline workload with a gap that varies in x and y (asperity, num 1) and a cross flow V = 0.05",
             "value": cells * args.steps / w2 / 1e6, "unit": "Mcell-updates/s", "ms_per_step": w2 / args.steps * 1e3,
-            "kernel_ms": k2, "roofline": r2, "roofline_achieved_GBps": r2["achieved"], "roofline_frac": r2["frac"]}}
+            "kernel_ms": k2, "roofline": r2, "roofline_achieved_GBps": r2["achieved"], "roofline_frac": r2["frac"], "spread": spread(walls2)}}
         if not args.no_gp:
             out["variants"]["gp_2048x2048_512pts"] = gp_variant(max(2, min(args.steps, 10)))
+            if not args.no_cpu:
+                out["variants"]["gp_2048x2048_512pts"]["cpu_baseline"] = gp_cpu_baseline()
             out["variants"]["gp_slab_1024x8192_rank3of8_512pts"] = gp_slab_variant(max(2, min(args.steps, 6)))
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline()
@@ -217,6 +233,41 @@ gp:
 db: {{init_size: {nt}, init_method: lhc, init_width: 0.01, init_seed: 123}}
 """
 FP64_PEAK_TFLOPS = 78.6         # MI355X fp64 vector = fp64 matrix dense peak (SURVEY.md 7 H2 / 8d)
+
+
+def gp_isa_counts():
+    """fp64 / other VALU instructions per Matern evaluation in k_gp_mean's inner loop, counted in the gfx950 assembly
+    (tools/gp_isa_count.py -> profiles/r03_gp/isa_counts_k_gp_mean.json); None if the file is absent."""
+    f = os.path.join(ROOT, 'profiles', 'r03_gp', 'isa_counts_k_gp_mean.json')
+    return json.load(open(f)) if os.path.exists(f) else None
+
+
+def gp_cpu_baseline(n=128, ntrain=512, steps=2):
+    """The oracle's stage-wise step with the three surrogates (oracle/gp.py, NumPy / SciPy: the restatement of the reference's
+    tinygp path, which cannot run here) on a crop of the same YAML: n x n cells, `ntrain` points, hyper-parameters at their
+    initial values.  Bounded sample: ~10-20 s on one core."""
+    import io
+    from oracle.config import read_yaml_input
+    from oracle.problem import OracleProblem
+    from oracle import gp as ogp
+    try:
+        from threadpoolctl import threadpool_limits
+        one_thread = threadpool_limits(limits=1, user_api='blas')
+    except ImportError:
+        one_thread = contextlib.nullcontext()
+    with contextlib.redirect_stdout(sys.stderr), one_thread:
+        d = read_yaml_input(io.StringIO(GP_YAML.format(n=n, nt=ntrain)))
+        p = OracleProblem.from_dict(d)
+        ogp.attach(p, d, optimise=False)
+        p._pre_run()
+        p.update()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            p.update()
+        dt = time.perf_counter() - t0
+    return {"value": n * n * steps / dt / 1e6, "unit": "Mcell-updates/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/ stage-wise step with three GP closures (NumPy / SciPy restatement of the reference's tinygp path, BLAS held to "
+                      f"one thread; host has {os.cpu_count()} cores), same YAML at {n}x{n}, {ntrain} training points, {steps} steps, {dt:.1f} s"}
 
 
 def gp_variant(steps, n=2048, ntrain=512):
@@ -260,6 +311,21 @@ def gp_variant(steps, n=2048, ntrain=512):
     evals = cells * ntrain * sum(per_step)
     flops_mean = cells * ntrain * (per_step[0] * (3 * 2 + 12) + (per_step[1] + per_step[2]) * (3 * 3 + 12))
     flops_var = cells * ntrain**2
+    # issue-level view: what the vector ALUs were asked to do.  One wave64 VALU instruction occupies a SIMD for 4 cycles whatever
+    # its type, so the chip issues 256 CUs x 4 SIMDs x 16 lanes x clock = 39.3e12 lane-instructions/s at 2.4 GHz (= 78.6 TFLOP/s / 2).
+    isa = gp_isa_counts()
+    issue = None
+    if isa:
+        per_model = {'pressure': isa['k_gp_mean<2, 1, false>'], 'shear': isa['k_gp_mean<3, 2, false>']}
+        ev = [cells * ntrain * per_step[0], cells * ntrain * (per_step[1] + per_step[2])]
+        fp64 = ev[0] * per_model['pressure']['fp64_per_evaluation'] + ev[1] * per_model['shear']['fp64_per_evaluation']
+        valu = fp64 + ev[0] * per_model['pressure']['other_valu_per_evaluation'] + ev[1] * per_model['shear']['other_valu_per_evaluation']
+        peak = FP64_PEAK_TFLOPS / 2 * 1e12
+        issue = {"fp64_instructions_per_evaluation": {k: v['fp64_per_evaluation'] for k, v in per_model.items()},
+                 "other_valu_instructions_per_evaluation": {k: v['other_valu_per_evaluation'] for k, v in per_model.items()},
+                 "fp64_issue_frac": fp64 / t_step / peak, "valu_issue_frac": valu / t_step / peak,
+                 "peak_lane_instructions_per_s": peak,
+                 "source": "static count in the gfx950 ISA of k_gp_mean's inner loop, profiles/r03_gp/isa_counts_k_gp_mean.json (tools/gp_isa_count.py)"}
     return {
         "workload": f"2D slider {n}x{n}, GP closures (pressure d=2, wall shear xz/yz d=3, Matern-3/2 ARD), {ntrain} training "
                     "points (LHC seed 123), hyper-parameters fixed (BASELINE.json configs[3])",
@@ -268,7 +334,7 @@ def gp_variant(steps, n=2048, ntrain=512):
         "roofline": {"bound": "fp64_valu", "achieved": flops_mean / t_step / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": flops_mean / t_step / 1e12 / FP64_PEAK_TFLOPS, "traffic": None,
                      "kernel": "k_gp_mean (whole stage-wise step timed: ~95 % of it is the posterior-mean passes)",
-                     "algorithmic_flops_per_step": flops_mean,
+                     "algorithmic_flops_per_step": flops_mean, "issue_level": issue,
                      "posterior_mean_passes_per_step": {"pressure": per_step[0], "shear_xz": per_step[1], "shear_yz": per_step[2],
                                                         "pressure_reused_from_sound_speed_pass": (r1 - r0) / steps}},
         "variance_pass": {"ms": t_var * 1e3, "model": "pressure",

@@ -126,8 +126,22 @@ __device__ __forceinline__ double lane_from_above(double v) {          // lane l
 // compiler's stores in between only make the wait stricter, never unsafe).  Form (ii) of the CDNA4 guide, section 5.7:
 // "=v" loads, then one wait statement naming every destination "+v" before the first consumer.
 typedef double dpair __attribute__((ext_vector_type(2)));
+// Cache policy of the march's traffic.  Every byte of q is written once per step and not read again before the next launch, so
+// nothing is gained by keeping the stores in L2 / the Infinity Cache, and on this chip streaming with the non-temporal hint is
+// measurably faster: an elementwise 3-in / 3-out kernel of the benchmark's size moves 5.7 TB/s with plain accesses and 6.5 TB/s
+// with `nt` ones (tools/stream_probe.hip, profiles/r03_stream/).  In the march (one box, alternating runs, 4096^2, x-only gap /
+// 2-D gap kernel): plain 189.6 / 279.0 us, nt stores 166.6 / 254.3, nt loads 195.8 / 265.4, both 178.4 / 261.8 -- the loads
+// share their halo lines (two columns, two rows per window) with the neighbouring waves through L2, which the hint shortens.
+// GPF_K2_NT: bit 0 loads, bit 1 stores; default: stores only.
+#ifndef GPF_K2_NT
+#define GPF_K2_NT 2
+#endif
 __device__ __forceinline__ void asm_load16(dpair& dst, const double* lane_ptr) {
+#if GPF_K2_NT & 1
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(lane_ptr) : "memory");
+#else
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(lane_ptr) : "memory");
+#endif
 }
 template <int N>
 __device__ __forceinline__ void asm_wait3(dpair& a, dpair& b, dpair& c) {
@@ -498,7 +512,14 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
                 const int ixo = D > 0 ? n - 1 : L.Nx + 2 - n;
                 const long long rbo = (long long)ixo * L.pitch;     // wave-uniform
                 auto st16 = [&](double* __restrict__ rowp, double va, double vb) {
-                    *reinterpret_cast<double2*>(reinterpret_cast<char*>(rowp) + lane_bytes) = D > 0 ? make_double2(va, vb) : make_double2(vb, va);
+                    dpair v;
+                    v.x = D > 0 ? va : vb; v.y = D > 0 ? vb : va;
+                    dpair* p = reinterpret_cast<dpair*>(reinterpret_cast<char*>(rowp) + lane_bytes);
+#if GPF_K2_NT & 2
+                    __builtin_nontemporal_store(v, p);
+#else
+                    *p = v;
+#endif
                 };
                 auto st8 = [&](double* __restrict__ rowp, unsigned int bytes, double v) {
                     *reinterpret_cast<double*>(reinterpret_cast<char*>(rowp) + bytes) = v;

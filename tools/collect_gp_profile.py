@@ -16,7 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PASSES = [['SQ_ACTIVE_INST_VALU', 'SQ_INSTS_VALU', 'SQ_BUSY_CYCLES', 'SQ_WAVES'], ['SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_VALU_MFMA_MOPS_F64'],
-          ['GRBM_GUI_ACTIVE', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY']]
+          ['SQ_INSTS_MFMA', 'SQ_BUSY_CU_CYCLES'], ['GRBM_GUI_ACTIVE', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY']]
 
 
 def main():
