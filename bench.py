@@ -297,6 +297,7 @@ def gp_variant(steps, n=2048, ntrain=512):
         sc = prob._scalars()                            # drains the stream
         t_step = (time.perf_counter() - t0) / steps
         p1, r1 = passes()
+        factorisation = prob._lib.gpf_gp_factorisation().decode()
         p1[0] -= 1                                      # the pass of the closing _scalars() call is outside a step
         per_step = [(b - a) / steps for a, b in zip(p0, p1)]
         assert sc.invalid == 0 and prob.step == steps + 1, "GP steps were skipped or went invalid"
@@ -330,7 +331,7 @@ def gp_variant(steps, n=2048, ntrain=512):
         "workload": f"2D slider {n}x{n}, GP closures (pressure d=2, wall shear xz/yz d=3, Matern-3/2 ARD), {ntrain} training "
                     "points (LHC seed 123), hyper-parameters fixed (BASELINE.json configs[3])",
         "value": n * n / t_step / 1e6, "unit": "Mcell-updates/s", "ms_per_step": t_step * 1e3, "steps": steps,
-        "matern_kernel_evaluations_per_s": evals / t_step,
+        "matern_kernel_evaluations_per_s": evals / t_step, "factorisation": factorisation,
         "roofline": {"bound": "fp64_valu", "achieved": flops_mean / t_step / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": flops_mean / t_step / 1e12 / FP64_PEAK_TFLOPS, "traffic": None,
                      "kernel": "k_gp_mean (whole stage-wise step timed: ~95 % of it is the posterior-mean passes)",

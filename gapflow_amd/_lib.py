@@ -105,6 +105,7 @@ SIGNATURES = {
     'gpf_gp_set_model': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), _DP, _DP, _DP,
                                    C.c_double, _DP, C.c_double, C.c_double]),
     'gpf_gp_clear_model': (C.c_int, [C.c_void_p, C.c_int]),
+    'gpf_gp_factorisation': (C.c_char_p, []),
     'gpf_gp_set_scales': (C.c_int, [C.c_void_p, C.c_int, _DP, C.c_double]),
     'gpf_gp_variance': (C.c_int, [C.c_void_p, C.c_int, C.c_int, _DP]),
     'gpf_gp_pass_counts': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
@@ -154,14 +155,17 @@ def _pin_hip_runtime():
 
 
 def _preload_rocsolver():
-    """GPF_USE_ROCSOLVER=1: map rocBLAS and the rocSOLVER that lies NEXT TO it now, before this process makes its first HIP
-    call.  Round 2 recorded a dlopen of rocSOLVER that did not return within 500 s when issued after the HIP runtime was up,
+    """Unless GPF_USE_ROCSOLVER=0: map rocBLAS and the rocSOLVER that lies NEXT TO it now, before this process makes its first HIP
+    call (rocSOLVER's dpotrf / dpotrs are the default factorisation of the GP kernel matrices).  Round 2 recorded a dlopen of rocSOLVER that did not return within 500 s when issued after the HIP runtime was up,
     and an abort when two rocBLAS images met (profiles/r03_rocsolver/README.md): the library itself only ever binds to
     images already mapped or to the copy beside its rocBLAS (csrc/gp_kernels.hip: roclibs), and this puts them there early."""
-    if os.environ.get('GPF_USE_ROCSOLVER') != '1':
+    if os.environ.get('GPF_USE_ROCSOLVER') == '0':
         return
     path = os.environ.get('GPF_ROCBLAS_PATH')
-    blas = C.CDLL(path if path and os.path.exists(path) else 'librocblas.so.5', mode=C.RTLD_GLOBAL)
+    try:
+        blas = C.CDLL(path if path and os.path.exists(path) else 'librocblas.so.5', mode=C.RTLD_GLOBAL)
+    except OSError:
+        return                          # no rocBLAS here: the GP entry points will say so when they are called
     info = _DlInfo()
     libdl = C.CDLL(None)
     libdl.dladdr.argtypes, libdl.dladdr.restype = [C.c_void_p, C.POINTER(_DlInfo)], C.c_int
@@ -170,7 +174,10 @@ def _preload_rocsolver():
     here = os.path.dirname(info.dli_fname.decode())
     for name in ('librocsolver.so.0', 'librocsolver.so'):
         if os.path.exists(os.path.join(here, name)):
-            C.CDLL(os.path.join(here, name), mode=C.RTLD_GLOBAL)
+            try:
+                C.CDLL(os.path.join(here, name), mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
             return
 
 

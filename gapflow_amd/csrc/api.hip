@@ -131,6 +131,7 @@ struct gpf_handle {
     Strip2Geom geom2[2];
     int nchunks2 = 0, nblocks2 = 0, npartials2_cap = 0, nblock_partials_cap = 0;
     bool plan2_valid = false;
+    bool nt_stores2 = false;                // k_step2 writes q with the non-temporal hint (plan_step2)
 };
 
 static int enter(gpf_handle* h, bool reads_only) {
@@ -705,6 +706,12 @@ static int plan_step2(gpf_handle* h) {
         HIP_TRY(hipMalloc(&h->block_partials, (size_t)cap * sizeof(Partial)));
         h->nblock_partials_cap = cap;
     }
+    // Non-temporal stores where a step streams more than the 256-MiB Infinity Cache holds (q read + q written + the topography
+    // planes if they are read); below that the previous step's output is still on the die when the next step loads it.
+    // GPF_NT_STORES=0/1 overrides (A/B runs).
+    const double streamed = (double)L.plane * 8.0 * (6 + (topo_mode_of(h) == 0 ? 3 : 0) + (h->Ls ? 1 : 0));
+    h->nt_stores2 = streamed > 192.0 * 1024 * 1024;
+    if (const char* s = std::getenv("GPF_NT_STORES")) h->nt_stores2 = std::atoi(s) != 0;
     h->plan2_valid = true;
     return GPF_OK;
 }
@@ -749,7 +756,7 @@ static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, doubl
     a2.g1x = h->g1; a2.g1y = h->g1 + 3 * L.pitch;
     a2.st = h->st; a2.partials = h->partials; a2.block_partials = h->block_partials; a2.arrive = h->arrive;
     a2.log = h->log; a2.log_base = log_base; a2.log_cap = h->log_cap;
-    a2.L = L; a2.E = h->E; a2.G = G2; a2.nchunks = h->nchunks2; a2.fused = fused ? 1 : 0; a2.honor_stop = honor_stop;
+    a2.L = L; a2.E = h->E; a2.G = G2; a2.nchunks = h->nchunks2; a2.fused = (fused ? 1 : 0) | (h->nt_stores2 ? 2 : 0); a2.honor_stop = honor_stop;
     GhostArgs g;
     GPF_TRY(ghost_args(h, honor_stop, g));
     const bool slab = slab_out != nullptr;

@@ -13,7 +13,7 @@
 // needs a dense solve: cells are processed in tiles, Ks of a tile is built, rocBLAS dtrsm (the one
 // MFMA-shaped operation of the path) forms L^-1 Ks and a column-norm kernel finishes.
 // The Cholesky factorisation and alpha come from the in-library k_gp_potrf / k_gp_potrs (default) or from
-// rocSOLVER dpotrf / dpotrs (GPF_USE_ROCSOLVER=1); rocBLAS / rocSOLVER are dlopen'ed so that a process
+// rocSOLVER dpotrf / dpotrs (the default; GPF_USE_ROCSOLVER=0: the in-library blocked Cholesky); rocBLAS / rocSOLVER are dlopen'ed so that a process
 // which also hosts PyTorch binds to the copies already mapped.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -510,8 +510,8 @@ __global__ void k_gp_nll_matrix(const double* __restrict__ X, int n, double amp,
 // In-library Cholesky factorisation K = L L^T (lower, in place, column-major) for the few-hundred-point
 // training sets of the surrogates: one 1024-thread workgroup, right-looking, the matrix stays in L2
 // (512^2 doubles = 2 MB).  *info = 0, or j+1 if the leading minor of order j+1 is not positive definite
-// (LAPACK dpotrf convention).  rocSOLVER's dpotrf is the alternative (GPF_USE_ROCSOLVER=1); its 930 MB
-// shared object costs ~100 s to map on a cold node, which no 45-MFLOP factorisation can repay.
+// (LAPACK dpotrf convention).  The fall-back of rocSOLVER's dpotrf (roclibs(): GPF_USE_ROCSOLVER=0, or no rocSOLVER beside the
+// rocBLAS in use), and the second opinion the tests hold rocSOLVER against.
 // A: n x n block with leading dimension lda, lower triangle factorised in place.  *info is written only on failure
 // (first non-positive pivot, 1-based, offset by `row0` for a diagonal block of a larger matrix) or, with row0 == 0, reset.
 __global__ __launch_bounds__(1024) void k_gp_potrf(double* A, int n, int lda, int row0, int* info) {
@@ -678,8 +678,12 @@ inline RocLibs& roclibs() {
     R.gemm = (RocLibs::gemm_t)dlsym(hb, "rocblas_dgemm");
     R.ok = R.create && R.destroy && R.set_stream && R.trsm;
     if (!R.ok) { R.err = "rocBLAS symbols missing"; return R; }
+    // rocSOLVER's dpotrf / dpotrs factorise the kernel matrices unless GPF_USE_ROCSOLVER=0 (then, or where no rocSOLVER lies next
+    // to the rocBLAS in use, the in-library blocked Cholesky does: gp_cholesky in api_gp.inc).  GPF_USE_ROCSOLVER=1 makes a
+    // missing rocSOLVER an error instead of a fall-back.
     const char* use = getenv("GPF_USE_ROCSOLVER");
-    if (use && use[0] == '1') {
+    const bool required = use && use[0] == '1';
+    if (!use || use[0] != '0') {
         void* hs = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
         const std::string dir = dir_of_symbol((void*)R.create);
         for (const char* name : {"/librocsolver.so.0", "/librocsolver.so"})
@@ -688,7 +692,8 @@ inline RocLibs& roclibs() {
             R.potrf = (RocLibs::potrf_t)dlsym(hs, "rocsolver_dpotrf");
             R.potrs = (RocLibs::potrs_t)dlsym(hs, "rocsolver_dpotrs");
         }
-        if (!R.potrf || !R.potrs) {
+        if (!R.potrf || !R.potrs) R.potrf = nullptr, R.potrs = nullptr;
+        if (!R.potrf && required) {
             R.ok = false;
             err_text = "GPF_USE_ROCSOLVER=1 but no rocSOLVER lies next to the rocBLAS in use (" + dir + "): a copy of another ROCm release is not loaded";
             R.err = err_text.c_str();

@@ -89,7 +89,7 @@ struct Step2Args {
     LogEntry* log; long long log_base, log_cap;
     Layout L; Edges E; Strip2Geom G;
     int nchunks;
-    int fused;
+    int fused;                              // bit 0: edge work inside this kernel; bit 1: non-temporal stores (plan_step2)
     int honor_stop;
 };
 
@@ -203,7 +203,8 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
                                             double (*stash)[128], Acc& result) {
     const Layout L = a.L;
     const Strip2Geom G = a.G;
-    const bool fused = a.fused != 0;
+    const bool fused = (a.fused & 1) != 0;
+    const bool nt_stores = (a.fused & 2) != 0;      // (rides in the same word: the march has no scalar register to spare)
 
     // ---- columns of this lane ----
     const bool y_periodic = a.E.rule[2][0] == BC_P;
@@ -516,7 +517,9 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
                     v.x = D > 0 ? va : vb; v.y = D > 0 ? vb : va;
                     dpair* p = reinterpret_cast<dpair*>(reinterpret_cast<char*>(rowp) + lane_bytes);
 #if GPF_K2_NT & 2
-                    __builtin_nontemporal_store(v, p);
+                    // (only where the step's working set exceeds the 256-MiB Infinity Cache: a small grid -- one rank's slab of the
+                    // 8-GPU run, 2 x 50 MB -- finds its previous output still on the die, and bypassing it costs 5 %)
+                    if (nt_stores) __builtin_nontemporal_store(v, p); else *p = v;
 #else
                     *p = v;
 #endif
@@ -699,7 +702,7 @@ void k_step2(const Step2Args a, const Phys P) {
     own.zero();
     if (active) step_strip2<EOS, HAS_LS, PIEZO, D, TOPO>(a, P, qin, qout, strip, chunk, lane, stash[wv], own);
 
-    if (!a.fused) {
+    if (!(a.fused & 1)) {
         if (active && lane == 0) {
             Partial p;
             p.ekin = own.ekin; p.vmax2 = own.v2; p.c2max = own.c2; p.flags = (double)own.flags;

@@ -8,8 +8,7 @@ Mirrors (reference paths):
 
 What runs where.  Per time step the posterior mean (every stage), the predictive variance and the GP
 sound speed are HIP kernels (csrc/gp_kernels.hip) fed by a device-resident Cholesky factor (gpf_gp_set_model:
-in-library blocked Cholesky by default, rocSOLVER dpotrf/dpotrs with GPF_USE_ROCSOLVER=1; the variance solve is
-rocBLAS dtrsm).  Hyper-parameter training -- a handful of marginal-likelihood evaluations on <= a few
+rocSOLVER dpotrf / dpotrs; GPF_USE_ROCSOLVER=0 or a missing rocSOLVER: the in-library blocked Cholesky).  Hyper-parameter training -- a handful of marginal-likelihood evaluations on <= a few
 hundred points, run only when the database grows (gp.py:461-465) -- stays on the host with SciPy BFGS, the
 optimiser the reference reaches through jaxopt.ScipyMinimize (gp.py:320-321).  Persistence of training data
 in dtool datasets and the LAMMPS runners are out of scope; the database lives in memory.

@@ -259,9 +259,11 @@ int gpf_close_step(gpf_handle* h, gpf_scalars_t* out);
 /* ---- GP surrogate closure: GaPFlow/models/gp.py, models/stress.py ------------------------------ */
 /* Stateless fit: K = A (1 + sqrt3 r) exp(-sqrt3 r) + sigma^2 I with r = ||inv_scale o (x - x')||
  * (gp.py:598-603; tinygp GaussianProcess(kernel, X, diag=yerr^2)), Cholesky K = L L^T and alpha = K^-1 Y
- * on the device: the library's own one-workgroup potrf/potrs kernels by default, rocSOLVER dpotrf/dpotrs
- * when GPF_USE_ROCSOLVER=1 (its 930 MB shared object takes ~100 s to map on a cold node).  Xn [n][d] and Yn [n][m] row-major, already normalised.  Outputs (host,
+ * on the device: rocSOLVER's dpotrf / dpotrs (the copy that lies beside the rocBLAS the process uses); with GPF_USE_ROCSOLVER=0,
+ * or where there is no such copy, the library's own blocked Cholesky.  Xn [n][d] and Yn [n][m] row-major, already normalised.  Outputs (host,
  * each may be NULL): L [n][n] row-major lower factor, alpha [n][m], logdet = log det K. */
+/* Which factorisation serves this process: "rocsolver_dpotrf", "in-library blocked Cholesky", or the reason neither is available. */
+const char* gpf_gp_factorisation(void);
 int gpf_gp_fit(int device, int n, int d, int m, const double* Xn, const double* Yn, double amp,
                const double* inv_scale, double sigma, double* L, double* alpha, double* logdet);
 /* Attach / replace a surrogate of this problem: which = 0 pressure (m = 1; writes the pressure field),

@@ -504,50 +504,84 @@ db: {{init_size: 400, init_method: lhc, init_width: 0.001}}
 
 
 def test_rocsolver_factorisation_equals_the_in_library_one(hiplib, tmp_path):
-    """BASELINE.json's north star names 'a rocSOLVER Cholesky'.  The default is the in-library blocked factorisation
-    (librocsolver.so is 930 MB and maps slowly; the matrices have a few hundred rows); GPF_USE_ROCSOLVER=1 switches
-    gpf_gp_fit / gpf_gp_set_model to rocsolver_dpotrf / dpotrs.  The switch is read once per process: a child process
-    runs the rocSOLVER path, this one the default, and L, alpha and log det K must agree (and match SciPy).
-
-    Opt-in (GPF_TEST_ROCSOLVER=1): on the MI355X pool the dlopen of librocsolver.so inside an initialised HIP process did
-    not return within 500 s (profiles/r02_rocsolver_load/), longer than the pool's silence limit for a running command."""
-    if os.environ.get('GPF_TEST_ROCSOLVER') != '1':
-        pytest.skip('rocSOLVER does not load in usable time on this pool (profiles/r02_rocsolver_load/README.md); '
-                    'set GPF_TEST_ROCSOLVER=1 to run the comparison')
+    """BASELINE.json's north star names 'a rocSOLVER Cholesky': gpf_gp_fit / gpf_gp_set_model / gpf_gp_nll_eval factorise with
+    rocsolver_dpotrf / dpotrs (the copy beside the rocBLAS in use, mapped before the first HIP call: csrc/gp_kernels.hip roclibs(),
+    _lib._preload_rocsolver; the hang and the abort of round 2 were a rocSOLVER of ROCm 7.2 meeting the HIP runtime and rocBLAS of
+    the ROCm 7.0 that PyTorch bundles, profiles/r03_rocsolver/).  GPF_USE_ROCSOLVER=0 selects the in-library blocked Cholesky;
+    the switch is read once per process: a child process runs that one, this process the default, and L, alpha and log det K
+    must agree (and match SciPy)."""
     import subprocess
     import sys
+    from scipy.linalg import lapack
     from gapflow_amd import _lib
     rng = np.random.default_rng(4)
     n, dd, m = 300, 3, 2
     X = rng.uniform(0.5, 1.0, (n, dd))
     Y = np.column_stack([np.sin(4 * X[:, 0]) + X[:, 2]**2, np.cos(3 * X[:, 1])]) + 0.01 * rng.standard_normal((n, m))
     amp, inv_scale, sigma = 1.2, np.array([2.0, 0.8, 1.5]), 0.05
-    np.savez(tmp_path / 'in.npz', X=X, Y=Y, inv_scale=inv_scale)
+    # second case: the numerically singular kernel matrix of a trained surrogate (see the test above)
+    Xs, Ys, ss = singular_training_set()
+    ths = np.array([11.70824469, 2.93533174, 14.77329233])
+    np.savez(tmp_path / 'in.npz', X=X, Y=Y, inv_scale=inv_scale, Xs=Xs, Ys=Ys, ss=ss, ths=ths)
     code = f"""
 import ctypes as C, numpy as np, sys
 sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
 from gapflow_amd import _lib
 lib = _lib.require_device()
 z = np.load({repr(str(tmp_path / 'in.npz'))})
-X, Y, sc = _lib.f64c(z['X']), _lib.f64c(z['Y']), _lib.f64c(z['inv_scale'])
-n, d = X.shape; m = Y.shape[1]
-L, alpha, logdet = np.empty((n, n)), np.empty((n, m)), C.c_double(0)
-_lib.check(lib.gpf_gp_fit(0, n, d, m, _lib.as_dp(X), _lib.as_dp(Y), {amp}, _lib.as_dp(sc), {sigma}, _lib.as_dp(L), _lib.as_dp(alpha), C.byref(logdet)))
-np.savez({repr(str(tmp_path / 'out.npz'))}, L=L, alpha=alpha, logdet=logdet.value)
+out = dict(which=lib.gpf_gp_factorisation().decode())
+for tag, X, Y, amp, inv, sigma in (('', z['X'], z['Y'], {amp}, z['inv_scale'], {sigma}), ('s', z['Xs'], z['Ys'], float(np.exp(z['ths'][0])), np.exp(-z['ths'][1:]), float(z['ss']))):
+    X, Y, sc = _lib.f64c(X), _lib.f64c(Y), _lib.f64c(inv)
+    n, d = X.shape; m = Y.shape[1]
+    L, alpha, logdet = np.zeros((n, n)), np.zeros((n, m)), C.c_double(0)
+    _lib.check(lib.gpf_gp_fit(0, n, d, m, _lib.as_dp(X), _lib.as_dp(Y), amp, _lib.as_dp(sc), sigma, _lib.as_dp(L), _lib.as_dp(alpha), C.byref(logdet)))
+    out['L' + tag], out['alpha' + tag], out['logdet' + tag] = L, alpha, logdet.value
+np.savez({repr(str(tmp_path / 'out.npz'))}, **out)
 """
-    env = dict(os.environ, GPF_USE_ROCSOLVER='1')
+    env = dict(os.environ, GPF_USE_ROCSOLVER='0')
     res = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     z = np.load(tmp_path / 'out.npz')
-    L, alpha, logdet = np.empty((n, n)), np.empty((n, m)), C.c_double(0)
-    Xc, Yc, sc = _lib.f64c(X), _lib.f64c(Y), _lib.f64c(inv_scale)
-    assert 'GPF_USE_ROCSOLVER' not in os.environ
-    _lib.check(hiplib.gpf_gp_fit(0, n, dd, m, _lib.as_dp(Xc), _lib.as_dp(Yc), amp, _lib.as_dp(sc), sigma,
-                                 _lib.as_dp(L), _lib.as_dp(alpha), C.byref(logdet)))
+    assert str(z['which']) == 'in-library blocked Cholesky'
+    assert hiplib.gpf_gp_factorisation().decode() == 'rocsolver_dpotrf', 'rocSOLVER must be what factorises by default on this image'
+
+    def fit(X, Y, amp, inv, s):
+        L, alpha, logdet = np.zeros((len(X), len(X))), np.zeros((len(X), Y.shape[1])), C.c_double(0)
+        _lib.check(hiplib.gpf_gp_fit(0, len(X), X.shape[1], Y.shape[1], _lib.as_dp(_lib.f64c(X)), _lib.as_dp(_lib.f64c(Y)), amp, _lib.as_dp(_lib.f64c(inv)), s,
+                                     _lib.as_dp(L), _lib.as_dp(alpha), C.byref(logdet)))
+        return dict(L=L, alpha=alpha, logdet=logdet.value)
+    mine = fit(X, Y, amp, inv_scale, sigma)
     ref = ogp.Fit(X, Y, amp, inv_scale, sigma)
-    for name, got in (('rocSOLVER', z), ('in-library', dict(L=L, alpha=alpha, logdet=logdet.value))):
+    for name, got in (('in-library', z), ('rocSOLVER', mine)):
         np.testing.assert_allclose(np.tril(got['L']), ref.L, rtol=1e-9, atol=1e-12, err_msg=name)
         np.testing.assert_allclose(got['alpha'], ref.alpha, rtol=1e-7, atol=1e-9 * np.abs(ref.alpha).max(), err_msg=name)
         np.testing.assert_allclose(got['logdet'], ref.logdet, rtol=1e-11, err_msg=name)
-    np.testing.assert_allclose(np.tril(z['L']), np.tril(L), rtol=1e-10, atol=1e-13)
-    np.testing.assert_allclose(z['alpha'], alpha, rtol=1e-8, atol=1e-10 * np.abs(alpha).max())
+    np.testing.assert_allclose(np.tril(z['L']), np.tril(mine['L']), rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(z['alpha'], mine['alpha'], rtol=1e-8, atol=1e-10 * np.abs(mine['alpha']).max())
+    # the singular one: both must succeed where LAPACK does, with its factor (1e-4 of the largest entry; sigma-sized pivots)
+    amps, invs = float(np.exp(ths[0])), np.exp(-ths[1:])
+    Zs = Xs * invs
+    r = np.sqrt(3 * ((Zs[:, None, :] - Zs[None, :, :])**2).sum(-1))
+    K = amps * (1 + r) * np.exp(-r) + ss**2 * np.eye(len(Xs))
+    c, info = lapack.dpotrf(K, lower=True)
+    assert info == 0
+    sing = fit(Xs, Ys, amps, invs, ss)
+    for name, Lg in (('in-library', z['Ls']), ('rocSOLVER', sing['L'])):
+        e = np.abs(np.tril(Lg) - np.tril(c)).max() / np.abs(c).max()
+        assert e <= 1e-4 and np.diag(Lg).min() > 0.5 * ss, f'{name}: {e:.2e}'
+        print(f'[singular trained K, {name}] max |L - LAPACK| / max |L| = {e:.1e}, smallest pivot / sigma = {np.diag(Lg).min() / ss:.3f}')
+
+
+def singular_training_set():
+    """Training set of the pressure surrogate of a 64^2 slider with 256 Latin-hypercube points in a narrow box (bench.GP_YAML)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import GP_YAML
+    from gapflow_amd import Problem
+    text = GP_YAML.format(n=64, nt=256).replace('obs_stddev: 100., active_learning: False', 'obs_stddev: 1.e5, active_learning: False')
+    prob = Problem.from_string(text)
+    for m in prob._gp_models.values():
+        m.optimise = False
+    prob._pre_run()
+    m = prob._gp_models['zz']
+    return np.array(m.Xtrain), np.array(m.Ytrain), float(m.Yerr)
