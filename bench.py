@@ -107,6 +107,7 @@ def cpu_baseline(sample_n=2048, steps=10):
 
 
 REPEATS = int(os.environ.get('GPF_BENCH_REPEATS', 5))
+PLAN_NOTES = []            # gpf_plan_note of every problem time_problem has run, in order
 
 
 def time_problem(text, steps, warmup):
@@ -142,6 +143,7 @@ def time_problem(text, steps, warmup):
         _lib.check(lib.gpf_step_timed(prob._h, nk, C.byref(kt), C.byref(tt)))
         sc = prob._scalars()
         assert sc.invalid == 0 and sc.ekin == sc.ekin, "state went invalid during the benchmark"
+        PLAN_NOTES.append(lib.gpf_plan_note(prob._h).decode())
         del prob
     return t1 - t0, kt.value / nk, tt.value / nk, walls
 
@@ -186,6 +188,7 @@ def run_single(args):
     roof = roofline(kernel_ms, cells, BYTES_PER_CELL_LINE, 'line', "k_step2<DH, topography line>")
     roof["frac_survey_8d"] = BYTES_PER_CELL * cells / (kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS
     roof["all_kernels_ms_per_step"] = all_ms
+    roof["plan"] = PLAN_NOTES[-1]
     roof["note"] = ("x-only gap: 48 B per cell-update are compulsory (q read + q write), the topography is one triple per row; "
                     "frac_survey_8d prices the same launch at SURVEY.md 8(d)'s 72 B, which this workload does not move")
     out = {
@@ -206,6 +209,7 @@ def run_single(args):
         w2, k2, a2, walls2 = time_problem(text, args.steps, args.warmup)
         r2 = roofline(k2, cells, BYTES_PER_CELL, 'planes', "k_step2<DH, topography planes>")
         r2["all_kernels_ms_per_step"] = a2
+        r2["plan"] = PLAN_NOTES[-1]
         out["variants"] = {"asperity_gap_2d_V0.05": {
             "workload": f"as the headline workload with a gap that varies in x and y (asperity, num 1) and a cross flow V = 0.05",
             "value": cells * args.steps / w2 / 1e6, "unit": "Mcell-updates/s", "ms_per_step": w2 / args.steps * 1e3,

@@ -106,6 +106,7 @@ SIGNATURES = {
                                    C.c_double, _DP, C.c_double, C.c_double]),
     'gpf_gp_clear_model': (C.c_int, [C.c_void_p, C.c_int]),
     'gpf_gp_factorisation': (C.c_char_p, []),
+    'gpf_plan_note': (C.c_char_p, [C.c_void_p]),
     'gpf_gp_set_scales': (C.c_int, [C.c_void_p, C.c_int, _DP, C.c_double]),
     'gpf_gp_variance': (C.c_int, [C.c_void_p, C.c_int, C.c_int, _DP]),
     'gpf_gp_pass_counts': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

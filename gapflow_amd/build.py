@@ -62,7 +62,9 @@ def build_library(force=False, verbose=False, out=None, extra_flags=()):
         f.write(res.stderr)
     if res.returncode != 0:
         errs = [ln for ln in res.stderr.splitlines() if 'remark:' not in ln]
-        raise RuntimeError('hipcc failed:\n' + '\n'.join(errs[-60:]))
+        first = [i for i, ln in enumerate(errs) if ' error' in ln]        # the errors themselves (warnings follow them by the hundred)
+        shown = [ln for i in first[:8] for ln in errs[i:i + 6]] + ['...'] + errs[-10:]
+        raise RuntimeError('hipcc failed:\n' + '\n'.join(shown))
     if verbose:
         print('compiled', lib)
     return lib

@@ -124,6 +124,7 @@ struct gpf_handle {
     bool step_open = false;                 // an unfused step is in progress on buffer parity^1
     int open_parity = 0;
     bool has_q = false, has_topo = false, pre_run_done = false;
+    bool prev_state_valid = false;          // the OTHER q buffer holds the state before the last committed fused step (gpf_update_closures)
     long long host_step = 0;                // step count at the last sync
     long long next_step = 0;                // index of the next step to be enqueued (== device step unless halted)
     // two-columns-per-lane step kernel (step2_kernel.hip): window geometry per predictor direction [0: D=+1, 1: D=-1],
@@ -132,6 +133,8 @@ struct gpf_handle {
     int nchunks2 = 0, nblocks2 = 0, npartials2_cap = 0, nblock_partials_cap = 0;
     bool plan2_valid = false;
     bool nt_stores2 = false;                // k_step2 writes q with the non-temporal hint (plan_step2)
+    StepState* st_trial = nullptr;          // plan_step2's timing launches commit into this copy of the run state
+    char plan2_note[160] = "";              // how the plan was arrived at (gpf_plan_note)
 };
 
 static int enter(gpf_handle* h, bool reads_only) {
@@ -279,7 +282,7 @@ extern "C" int gpf_destroy(gpf_handle* h) {
     if (!h) return GPF_OK;
     hipSetDevice(h->cfg.device);
     void* ptrs[] = {h->q[0], h->q[1], h->topo, h->topo_line, h->Ls, h->g1, h->seam, h->halo, h->beyond, h->st, h->partials, h->arrive, h->block_partials, h->spart,
-                    h->log, h->stage, h->fields, h->work, h->gpvar, h->gp_state_mean, h->gpscratch, h->gptile,
+                    h->log, h->stage, h->fields, h->work, h->st_trial, h->gpvar, h->gp_state_mean, h->gpscratch, h->gptile,
                     h->gp[0].Z, h->gp[0].alpha, h->gp[0].L, h->gp[1].Z, h->gp[1].alpha, h->gp[1].L,
                     h->gp[2].Z, h->gp[2].alpha, h->gp[2].L, h->gp[0].Linv, h->gp[1].Linv, h->gp[2].Linv, h->gp[0].W, h->gp[1].W, h->gp[2].W};
     if (h->blas && roclibs().ok) roclibs().destroy(h->blas);
@@ -395,6 +398,7 @@ extern "C" int gpf_upload(gpf_handle* h, int field, const double* host, size_t c
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (field == GPF_FIELD_Q) h->has_q = true;
     h->g1_ready = false;
+    h->prev_state_valid = false;
     if (field == GPF_FIELD_TOPO) h->has_topo = true;
     return GPF_OK;
 }
@@ -445,6 +449,7 @@ static FieldPtrs field_ptrs(gpf_handle* h) {
 }
 
 static int gp_launch_mean(gpf_handle* h, int which, const double* q, bool with_grad, double* c2_out);
+static int read_state(gpf_handle* h, StepState& s);
 
 // thinning on a slab: the beyond rows that belong to field q (the working field of an open step, or the state)
 static const double* beyond_rows(gpf_handle* h, const double* q) {
@@ -487,7 +492,36 @@ extern "C" int gpf_update_closures(gpf_handle* h) {
     GPF_TRY(enter(h));
     int par = 0;
     GPF_TRY(current_parity(h, &par));
-    GPF_TRY(launch_fields(h, h->q[par]));
+    if (h->prev_state_valid && !h->E.halo[0] && !h->E.halo[1]) {
+        // What the reference's pressure / wall-stress / bulk-stress fields hold after update() are the closures of the CORRECTOR
+        // stage, i.e. of the field the predictor left (problem.py:531-560; nothing re-evaluates them on the averaged state).  The
+        // fused step keeps neither that field nor its closures, but the state it started from is still in the other buffer: the
+        // predictor stage is run again on it, reference order, with the step size and sweep direction of that step, and the
+        // closures are evaluated on the result.  (A slab would need its neighbours' predictor rows: it evaluates on the state.)
+        const Layout& L = h->L;
+        StepState s;
+        GPF_TRY(read_state(h, s));
+        double* w = h->q[par ^ 1];
+        const long long n = (long long)(L.Nx + 2) * (L.Ny + 2);
+        const int nb = blocks_for(n);
+        if (!h->work) HIP_TRY(hipMalloc(&h->work, (size_t)9 * L.plane * sizeof(double)));
+        GPF_TRY(launch_fields(h, w));
+        double *fx = h->work, *fy = h->work + 3 * L.plane, *src = h->work + 6 * L.plane;
+        FieldPtrs F = field_ptrs(h);
+        const int mc = h->cfg.mc_order;
+        const int sw = mc == 0 ? (((s.step - 1) % 2 == 0) ? 1 : -1) : mc;
+        const int dir = ((sw + 1) / 2) ? 1 : -1;
+        hipLaunchKernelGGL(k_fluxdiff, dim3(nb), dim3(256), 0, h->stream, w, F.p, F.tau, dir, fx, fy, L);
+        hipLaunchKernelGGL(k_source, dim3(nb), dim3(256), 0, h->stream, w, h->topo, F.tau, F.lower, F.upper, src, L);
+        hipLaunchKernelGGL(k_axpy, dim3(nb), dim3(256), 0, h->stream, w, fx, fy, src, (const double*)&h->st->dt_last, h->cfg.dx, h->cfg.dy, L);
+        hipLaunchKernelGGL(k_bc_x, dim3((L.Ny + 2 + 255) / 256), dim3(256), 0, h->stream, w, L, h->E);
+        hipLaunchKernelGGL(k_bc_y, dim3((L.Nx + 2 + 255) / 256), dim3(256), 0, h->stream, w, L, h->E);
+        HIP_TRY(hipGetLastError());
+        GPF_TRY(launch_fields(h, w));
+        h->prev_state_valid = false;        // the buffer now holds the predictor's field; the closures stay in the derived fields
+    } else {
+        GPF_TRY(launch_fields(h, h->q[par]));
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));
     return GPF_OK;
 }
@@ -587,6 +621,7 @@ extern "C" int gpf_pre_run(gpf_handle* h) {
     s.rbuf[0] = 1.0; s.rcount = 1; s.rhead = 0;
     s.converged = (1.0 < c.tol) ? 1 : 0;
     s.invalid = 0;
+    s.dt_last = 0.0;
     if (!h->pre_run_done) s.ekin_old = sc.ekin;     // otherwise keep a user-set kinetic_energy_old
     s.ekin = sc.ekin;
     s.vmax2 = sc.v_max * sc.v_max; s.c2max = sc.v_sound * sc.v_sound;
@@ -595,6 +630,7 @@ extern "C" int gpf_pre_run(gpf_handle* h) {
     GPF_TRY(write_state(h, s));
     h->pre_run_done = true;
     h->g1_ready = false;
+    h->prev_state_valid = false;
     h->host_step = 0; h->next_step = 0;
     return GPF_OK;
 }
@@ -666,30 +702,13 @@ static bool step2_fused(const gpf_handle* h) { return !h->split_edges; }
 constexpr int K2_LONG_MARCH_ROWS = 100;    // rows per wave from which plan_step2 runs one wave per SIMD instead of two
 
 // One wave marches over one row chunk of one 126-column strip; the chunks are sized so that all waves are resident at
-// once (a single round, no tail) when the problem is big enough: two waves per SIMD, or one where that still leaves
-// long marches.
-static int plan_step2(gpf_handle* h) {
-    if (h->plan2_valid) return GPF_OK;
+// once (a single round, no tail) when the problem is big enough: two waves per SIMD, or one.
+static int plan_apply(gpf_handle* h, int nchunks, bool nt) {
     const Layout& L = h->L;
-    h->geom2[0] = strip2_geom(L, 1);
-    h->geom2[1] = strip2_geom(L, -1);
     const int nstrips = std::max(h->geom2[0].nstrips, h->geom2[1].nstrips);
-    int nchunks = 0;
-    if (const char* s = std::getenv("GPF_CHUNKS")) nchunks = std::atoi(s);
-    if (nchunks <= 0) {
-        int per_cu = 0, ncu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)step2_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, 1, topo_mode_of(h)), 256, 0));
-        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->cfg.device));
-        const int resident_waves = std::max(1, per_cu * ncu) * 4;
-        nchunks = resident_waves / nstrips;
-        // Long marches run better with ONE wave per SIMD (half as many concurrent row streams into HBM, half the halo rows;
-        // the rows in flight ahead of each wave cover the latency alone): 3 % at 4096^2 (132 rows per wave) and at 6144^2,
-        // nothing at 3072^2 (76 rows), a loss below that (profiles/r02_ab_history.md).
-        const int one_per_simd = (ncu * 4) / nstrips;
-        if (one_per_simd >= 1 && L.Nx / one_per_simd >= K2_LONG_MARCH_ROWS) nchunks = one_per_simd;
-    }
     nchunks = std::max(1, std::min(nchunks, std::max(1, L.Nx / 4)));        // small grids: >= 4 rows per chunk
     h->nchunks2 = nchunks;
+    h->nt_stores2 = nt;
     const int nwaves = nstrips * nchunks;
     h->nblocks2 = (((nwaves + 3) / 4) + 7) / 8 * 8;
     if (nwaves > h->npartials2_cap) {
@@ -706,15 +725,108 @@ static int plan_step2(gpf_handle* h) {
         HIP_TRY(hipMalloc(&h->block_partials, (size_t)cap * sizeof(Partial)));
         h->nblock_partials_cap = cap;
     }
-    // Non-temporal stores where a step streams more than the 256-MiB Infinity Cache holds (q read + q written + the topography
-    // planes if they are read); below that the previous step's output is still on the die when the next step loads it.
-    // GPF_NT_STORES=0/1 overrides (A/B runs).
+    return GPF_OK;
+}
+
+static void fill_step2_args(gpf_handle* h, Step2Args& a2, int D, int honor_stop, long long log_base, double* slab_out, bool p2p);
+
+// Mean duration (us) of the fused step with the plan in force, on the handle's own field: the launches read the current state and
+// write the OTHER buffer (dead until the next step overwrites it) and commit into a copy of the run state, which is reset before
+// every launch -- nothing the solver will read changes.
+static int plan_trial(gpf_handle* h, int D, float* us) {
+    if (!h->st_trial) HIP_TRY(hipMalloc(&h->st_trial, sizeof(StepState)));
+    h->prev_state_valid = false;            // the launches below overwrite the other buffer
+    Step2Args a2;
+    fill_step2_args(h, a2, D, 0, 0, nullptr, false);
+    a2.st = h->st_trial; a2.log = nullptr;
+    const step2_kernel_t k2 = step2_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, D, topo_mode_of(h));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    const int reps = 6;
+    float total = 0.f;
+    for (int r = -1; r < reps; ++r) {       // r = -1: warm-up, not timed
+        HIP_TRY(hipMemcpyAsync(h->st_trial, h->st, sizeof(StepState), hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipEventRecord(e0, h->stream));
+        hipLaunchKernelGGL(k2, dim3(h->nblocks2), dim3(256), 0, h->stream, a2, h->P);
+        HIP_TRY(hipEventRecord(e1, h->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        if (r >= 0) total += ms;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    HIP_TRY(hipGetLastError());
+    *us = total / reps * 1e3f;
+    return GPF_OK;
+}
+
+// Which plan: waves per SIMD (row chunks per strip) and the cache policy of the stores.  Neither has a winner that holds across
+// kernels and boxes (paired in-process runs at 4096^2, tools/ab_inprocess.py: the x-only-gap kernel is 2-3 % faster with two
+// waves per SIMD and indifferent to the store policy, the 2-D-gap kernel 6 % faster with one wave per SIMD AND non-temporal
+// stores, 4 % with two waves and plain ones; round 2's runs on other boxes favoured one wave per SIMD for both), so grids of a
+// million cells and more TIME the candidates once, on their own data (plan_trial: ~8 ms per handle), and keep the fastest.
+// Smaller grids, slabs and GPF_PLAN_TUNE=0 take the rule of thumb; GPF_CHUNKS / GPF_NT_STORES pin a choice (A/B runs).
+static int plan_step2(gpf_handle* h, int D) {
+    if (h->plan2_valid) return GPF_OK;
+    const Layout& L = h->L;
+    h->geom2[0] = strip2_geom(L, 1);
+    h->geom2[1] = strip2_geom(L, -1);
+    const int nstrips = std::max(h->geom2[0].nstrips, h->geom2[1].nstrips);
+    int per_cu = 0, ncu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)step2_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, 1, topo_mode_of(h)), 256, 0));
+    HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->cfg.device));
+    const int all_resident = std::max(1, std::max(1, per_cu * ncu) * 4 / nstrips);      // every wave resident in one round (two per SIMD)
+    const int one_per_simd = (ncu * 4) / nstrips;
+    // Non-temporal stores can only pay where a step streams more than the 256-MiB Infinity Cache holds (q read + q written + the
+    // topography planes if they are read); below that the previous step's output is still on the die when the next step loads it.
     const double streamed = (double)L.plane * 8.0 * (6 + (topo_mode_of(h) == 0 ? 3 : 0) + (h->Ls ? 1 : 0));
-    h->nt_stores2 = streamed > 192.0 * 1024 * 1024;
-    if (const char* s = std::getenv("GPF_NT_STORES")) h->nt_stores2 = std::atoi(s) != 0;
+    const bool nt_possible = streamed > 192.0 * 1024 * 1024;
+    const char* env_chunks = std::getenv("GPF_CHUNKS");
+    const char* env_nt = std::getenv("GPF_NT_STORES");
+    const char* env_tune = std::getenv("GPF_PLAN_TUNE");
+    // rule of thumb: one wave per SIMD for long marches (>= 100 rows per wave), non-temporal stores where they can pay
+    int nchunks = all_resident;
+    if (one_per_simd >= 1 && L.Nx / one_per_simd >= K2_LONG_MARCH_ROWS) nchunks = one_per_simd;
+    bool nt = nt_possible;
+    if (env_chunks && std::atoi(env_chunks) > 0) nchunks = std::atoi(env_chunks);
+    if (env_nt) nt = std::atoi(env_nt) != 0;
+    const bool slab = h->E.halo[0] || h->E.halo[1];
+    const bool tune = !(env_tune && std::atoi(env_tune) == 0) && !slab && !h->split_edges && h->pre_run_done && (long long)L.Nx * L.Ny >= (1ll << 20) &&
+                      one_per_simd >= 1 && L.Nx / one_per_simd >= 16 && !(env_chunks && env_nt);
+    if (!tune) {
+        GPF_TRY(plan_apply(h, nchunks, nt));
+        std::snprintf(h->plan2_note, sizeof h->plan2_note, "%d chunks per strip, %s stores (rule of thumb%s)", h->nchunks2,
+                      h->nt_stores2 ? "non-temporal" : "plain", (env_chunks || env_nt) ? ", pinned by the environment" : "");
+        h->plan2_valid = true;
+        return GPF_OK;
+    }
+    float best = 0.f;
+    int best_chunks = nchunks;
+    bool best_nt = nt;
+    std::string seen;
+    for (int c : {one_per_simd, all_resident}) {
+        if (env_chunks && std::atoi(env_chunks) > 0) c = std::atoi(env_chunks);
+        for (int pol = 0; pol < (nt_possible && !env_nt ? 2 : 1); ++pol) {
+            const bool cand_nt = env_nt ? nt : (pol == 1);
+            GPF_TRY(plan_apply(h, c, cand_nt));
+            float us = 0.f;
+            GPF_TRY(plan_trial(h, D, &us));
+            char buf[48];
+            std::snprintf(buf, sizeof buf, " %d/%s %.0f", h->nchunks2, cand_nt ? "nt" : "plain", us);
+            seen += buf;
+            if (best == 0.f || us < best) { best = us; best_chunks = c; best_nt = cand_nt; }
+        }
+        if ((env_chunks && std::atoi(env_chunks) > 0) || one_per_simd == all_resident) break;
+    }
+    GPF_TRY(plan_apply(h, best_chunks, best_nt));
+    std::snprintf(h->plan2_note, sizeof h->plan2_note, "%d chunks per strip, %s stores (timed, us:%s)", h->nchunks2,
+                  h->nt_stores2 ? "non-temporal" : "plain", seen.c_str());
+    DBG("plan_step2: %s", h->plan2_note);
     h->plan2_valid = true;
     return GPF_OK;
 }
+
+extern "C" const char* gpf_plan_note(gpf_handle* h) { return h ? h->plan2_note : ""; }
 
 constexpr int SLAB_COMMIT_BLOCKS = 24;     // k_begin_slab without stage-1 work: a 6-row copy and the commit
 
@@ -741,27 +853,35 @@ static int ghost_args(gpf_handle* h, int honor_stop, GhostArgs& g) {
     return GPF_OK;
 }
 
-static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, double* slab_out,
-                        hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, bool p2p = false) {
+static void fill_step2_args(gpf_handle* h, Step2Args& a2, int D, int honor_stop, long long log_base, double* slab_out, bool p2p) {
     const Layout& L = h->L;
-    GPF_TRY(plan_step2(h));
-    const int mc = h->cfg.mc_order;
-    const int D = mc == 0 ? ((h->next_step % 2 == 0) ? 1 : -1) : (((mc + 1) / 2) ? 1 : -1);
-    h->next_step += 1;
     const bool fused = step2_fused(h);
     const Strip2Geom& G2 = h->geom2[D > 0 ? 0 : 1];
-    const int np_step = G2.nstrips * h->nchunks2;
-    Step2Args a2;
     a2.qa = h->q[0]; a2.qb = h->q[1]; a2.topo = h->topo; a2.topo_line = h->topo_line; a2.Ls = h->Ls;
     a2.g1x = h->g1; a2.g1y = h->g1 + 3 * L.pitch;
     a2.st = h->st; a2.partials = h->partials; a2.block_partials = h->block_partials; a2.arrive = h->arrive;
     a2.log = h->log; a2.log_base = log_base; a2.log_cap = h->log_cap;
     a2.L = L; a2.E = h->E; a2.G = G2; a2.nchunks = h->nchunks2; a2.fused = (fused ? 1 : 0) | (h->nt_stores2 ? 2 : 0); a2.honor_stop = honor_stop;
+    const bool slab = slab_out != nullptr;
+    for (int e = 0; e < 2; ++e) a2.seam[e] = (h->E.halo[e] == 2 && h->has_seam[e]) ? h->seam + (size_t)e * 8 * L.pitch : nullptr;
+    a2.out = slab_out; a2.msg = (slab && !p2p) ? h->halo : nullptr; a2.p2p = p2p_args(h, p2p);
+}
+
+static int enqueue_step(gpf_handle* h, int honor_stop, long long log_base, double* slab_out,
+                        hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, bool p2p = false) {
+    const Layout& L = h->L;
+    const int mc = h->cfg.mc_order;
+    const int D = mc == 0 ? ((h->next_step % 2 == 0) ? 1 : -1) : (((mc + 1) / 2) ? 1 : -1);
+    GPF_TRY(plan_step2(h, D));
+    h->next_step += 1;
+    const bool fused = step2_fused(h);
+    const Strip2Geom& G2 = h->geom2[D > 0 ? 0 : 1];
+    const int np_step = G2.nstrips * h->nchunks2;
     GhostArgs g;
     GPF_TRY(ghost_args(h, honor_stop, g));
+    Step2Args a2;
+    fill_step2_args(h, a2, D, honor_stop, log_base, slab_out, p2p);
     const bool slab = slab_out != nullptr;
-    a2.seam[0] = g.seam[0]; a2.seam[1] = g.seam[1];
-    a2.out = slab_out; a2.msg = (slab && !p2p) ? h->halo : nullptr; a2.p2p = p2p_args(h, p2p);
     FinishArgs f;
     f.partials = h->partials; f.st = h->st;
     f.log = h->log; f.log_base = log_base; f.log_cap = h->log_cap; f.out = slab_out; f.honor_stop = honor_stop;
@@ -883,6 +1003,7 @@ extern "C" int gpf_step(gpf_handle* h, int64_t n, int honor_stop, gpf_scalars_t*
             }
         }
         h->host_step = s.step; h->next_step = s.step;
+        h->prev_state_valid = ran >= 1 && !s.invalid;      // the other buffer: the state before the last step of this batch
         done += batch;
         if (ran < batch) break;     // stopped on the device (converged / max_it / invalid)
     }
@@ -915,6 +1036,7 @@ extern "C" int gpf_step_timed(gpf_handle* h, int64_t n, double* kernel_ms, doubl
     for (auto& e : ev) hipEventDestroy(e);
     StepState s;
     GPF_TRY(read_state(h, s));
+    h->prev_state_valid = s.step > h->host_step && !s.invalid;
     h->host_step = s.step; h->next_step = s.step;
     return rc;
 }

@@ -175,6 +175,7 @@ __device__ inline void commit_step(StepState* st, double ekin, double v2, double
         st->ekin = ekin; st->vmax2 = v2; st->c2max = c2;
         st->step += 1;
         st->simtime += st->dt;
+        st->dt_last = st->dt;
         if (st->adaptive) st->dt = st->CFL * dt_crit;
         st->parity ^= 1;
     }
@@ -766,9 +767,10 @@ __global__ __launch_bounds__(256) void k_source(const double* q, const double* h
 }
 
 // q <- q - dt (fX/dx + fY/dy - src) over the whole array (problem.py:558)
+// (dtp: the step size, read on the device: &st->dt for a step in progress, &st->dt_last when a finished step's predictor is redone)
 __global__ __launch_bounds__(256) void k_axpy(double* q, const double* fx, const double* fy, const double* src,
-                                              const StepState* st, double dx, double dy, Layout L) {
-    const double dt = st->dt;
+                                              const double* dtp, double dx, double dy, Layout L) {
+    const double dt = *dtp;
     const long long w = L.Ny + 2, n = (long long)(L.Nx + 2) * w;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const long long o = L.at((int)(i / w), (int)(i % w));

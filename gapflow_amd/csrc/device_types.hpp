@@ -46,6 +46,7 @@ struct StepState {
     int parity;             // which of the two q buffers holds the current state
     int invalid;            // 0 ok, 1 NaN, 2 negative density
     int converged;
+    double dt_last;         // step size of the last committed step (gpf_update_closures re-runs its predictor stage)
 };
 
 struct LogEntry {           // == gpf_scalars_t in include/gapflow_hip.h

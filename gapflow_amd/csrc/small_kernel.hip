@@ -79,6 +79,7 @@ __global__ __launch_bounds__(512) void k_small_steps(const SmallArgs a, const Ph
         __syncthreads();
     };
 
+    int committed = 0;                              // steps this launch has committed (block-uniform)
     for (int step = 0; step < a.nsteps; ++step) {
         if (st->invalid != 0 || (a.honor_stop && (st->converged || st->step >= st->max_it))) break;     // block-uniform
         const double dt = st->dt;
@@ -140,14 +141,19 @@ __global__ __launch_bounds__(512) void k_small_steps(const SmallArgs a, const Ph
         __syncthreads();
         if (sh_flags[1]) break;                     // rolled back: q0 still holds the last valid state
         double* tmp = q0; q0 = q; q = tmp;          // the averaged field is the current one now
+        committed += 1;
     }
     // the current state -> the buffer the (final) parity designates; the run state back to global memory
     __syncthreads();
     if (tid == 0) *a.st = sst;
     double* dst = st->parity ? a.qb : a.qa;
+    double* prev = st->parity ? a.qa : a.qb;        // ... and the state before the last committed step -> the other buffer, where the
+                                                    // launch-per-step kernels leave it too (gpf_update_closures redoes its predictor stage)
     for (int t = tid; t < nc; t += nt) {
         const long long o = G.at(t / w, t % w);
         for (int c = 0; c < 3; ++c) dst[c * G.plane + o] = q0[c * nc + t];
+        if (committed > 0 && st->invalid == 0)
+            for (int c = 0; c < 3; ++c) prev[c * G.plane + o] = q[c * nc + t];
     }
 }
 

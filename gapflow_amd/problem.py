@@ -433,9 +433,11 @@ class Problem:
             # (the corrector's), on the device; the host mirror of the topography is refreshed on access
             _lib.check(lib.gpf_elastic_update(h))
             self.topo.mark_stale()
-            self._closures_stale = True
         self._absorb([sc])
         self._mark_device_advanced()
+        # the derived fields on the device ARE what the reference's field objects hold now: the closures of the corrector stage
+        # (problem.py:531-560; neither the averaging nor Topography.update re-evaluates them)
+        self._closures_stale = False
 
     def _finalize(self, reason):
         # problem.py:588-610: the device kept the pre-step field; closures refresh lazily

@@ -143,6 +143,11 @@ int gpf_step(gpf_handle* h, int64_t n, int honor_stop, gpf_scalars_t* log, int64
  * (recorded on the handle's stream).  *kernel_ms = sum of the n kernel durations, *total_ms =
  * elapsed device time of the whole sequence (stage-1 ghost data, fused step, ghost fill with the commit). */
 int gpf_step_timed(gpf_handle* h, int64_t n, double* kernel_ms, double* total_ms);
+/* How the fused step of this handle is laid out on the chip (row chunks per strip = waves per SIMD, cache policy of the stores)
+ * and how that was decided: grids of a million cells and more time the candidates once on their own data before the first step
+ * (GPF_PLAN_TUNE=0: rule of thumb; GPF_CHUNKS / GPF_NT_STORES pin a choice).  Empty until the first step has been planned.
+ * The choice changes the order in which the kinetic energy is summed (last bits of the residual), nothing else. */
+const char* gpf_plan_note(gpf_handle* h);
 /* The reference-ordered, unfused stage pipeline (closures -> flux -> source -> axpy -> ghost),
  * one kernel per reference function; same results as gpf_step(h,1,...).  Kept for
  * cross-checking and for _finalize (problem.py:588-610). */

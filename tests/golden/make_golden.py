@@ -408,7 +408,9 @@ def run_case(name, spec, use_ref, perturb_seed=None):
         prob.update()
         hist.append([prob.step, prob.simtime, prob.dt, prob.kinetic_energy, prob.residual, prob.v_sound, prob.v_max, prob.mass])
         if s in spec['snaps']:
-            prob.update_closures()
+            # the pressure field as update() leaves it: the closure of the CORRECTOR stage, evaluated on the predictor's field
+            # (problem.py:531-560; nothing re-evaluates it on the averaged state) -- what `problem.pressure.pressure` and the
+            # frames of sol.nc hold in the reference
             res[f'q_{s}'] = prob.q.copy()
             res[f'p_{s}'] = prob.pressure.copy()
     res['history'] = np.array(hist)     # columns: step, time, dt(next), ekin, residual, vsound, vmax, mass

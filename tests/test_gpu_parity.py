@@ -53,8 +53,10 @@ def test_fused_step_matches_golden(hiplib, name):
             assert (err <= tol).all(), f'q at step {s}: err {err} tol {tol}'
             worst = np.maximum(worst, err / tol)
             achieved = np.maximum(achieved, err)
-            # p(rho): within 1e-9 of the pressure scale plus what the (already bounded) density error
-            # maps to through dp/drho = c^2 (up to 1e8 for the stiff Dowson-Higginson law)
+            # the pressure FIELD as the reference's update() leaves it -- the corrector stage's closure, evaluated on the
+            # predictor's field (problem.py:531-560; gpf_update_closures re-runs that stage from the retained previous state):
+            # within 1e-9 of the pressure scale plus what the (already bounded) density error maps to through
+            # dp/drho = c^2 (up to 1e8 for the stiff Dowson-Higginson law)
             drho = np.abs(prob.q[0] - fx[f'q_{s}'][0]).max()
             dp = np.abs(prob.pressure.pressure - fx[f'p_{s}']).max()
             assert dp <= 1e-9 * np.abs(fx[f'p_{s}']).max() + 2.0 * prob.pressure.v_sound**2 * drho, f'p at step {s}'

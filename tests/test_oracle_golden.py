@@ -80,6 +80,8 @@ def test_step_fixtures(name):
         prob.update()
         if s in snaps:
             np.testing.assert_allclose(prob.q, fx[f'q_{s}'], rtol=1e-12, atol=0)
+            # the pressure FIELD after update(): the corrector stage's, evaluated on the predictor's result (problem.py:531-560)
+            np.testing.assert_allclose(prob.pressure, fx[f'p_{s}'], rtol=1e-12, atol=0)
             row = fx['history'][s - 1]
             np.testing.assert_allclose([prob.simtime, prob.dt, prob.kinetic_energy, prob.v_sound], row[[1, 2, 3, 5]], rtol=1e-12)
 
