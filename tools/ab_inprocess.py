@@ -4,7 +4,10 @@ rounds of tools/ab_step.py on this pool -- hits both alike.  A variant = environ
 first step (GPF_NT_STORES, GPF_CHUNKS, GPF_TOPO_PLANES ...).
 
     python tools/ab_inprocess.py [--n 4096] [--batches 24] [--steps 40] [--gap journal|asperity] name:VAR=VAL[,VAR=VAL] ...
-    e.g. python tools/ab_inprocess.py plain:GPF_NT_STORES=0 nt:GPF_NT_STORES=1"""
+    e.g. python tools/ab_inprocess.py plain:GPF_NT_STORES=0 nt:GPF_NT_STORES=1
+
+`lib=path/to/variant.so` among a variant's settings loads ANOTHER build of the library into the same process (compile-time choices:
+python -m gapflow_amd.build --variant NAME -DGPF_ONLY_EOS_DH -D...); the handles of the variants are independent."""
 import ctypes as C
 import os
 import statistics
@@ -29,13 +32,25 @@ def main():
     if gap == 'asperity':
         text = text.replace("type: journal\n    CR: 1.e-2\n    eps: 0.7\n    U: 0.1\n    V: 0.",
                             "type: asperity\n    hmin: 2.e-6\n    hmax: 1.e-5\n    num: 1\n    U: 0.1\n    V: 0.05")
+    _lib.load()
     variants = []
     for a in args:
         name, rest = a.split(':', 1)
         env = dict(p.split('=', 1) for p in rest.split(',') if p)
+        libpath = env.pop('lib', None)
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
-        prob = Problem.from_string(text)
+        default_lib = _lib._lib
+        if libpath:                     # a second (third ...) build in this process: bound like the default one
+            other = C.CDLL(os.path.abspath(libpath))
+            for fname, (res, argt) in _lib.SIGNATURES.items():
+                fn = getattr(other, fname)
+                fn.restype, fn.argtypes = res, argt
+            _lib._lib = other
+        try:
+            prob = Problem.from_string(text)
+        finally:
+            _lib._lib = default_lib
         prob._pre_run()
         prob._advance(5, honor_stop=False)          # plans with this variant's environment
         for k, v in old.items():
