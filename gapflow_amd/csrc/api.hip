@@ -202,6 +202,20 @@ static int ensure_stage(gpf_handle* h, size_t doubles) {
     return GPF_OK;
 }
 
+// The buffers the step kernel streams.  What makes identical handles run at 167 or 183 us (profiles/r03_placement/) shows in the
+// translation counters -- the fast handles have the fewest translations in flight in the CUs' TLBs (TCP_CLIENT_UTCL1_INFLIGHT
+// 1.1e9 against 1.7e9 per launch) and the lowest read latency -- but asking for PHYSICALLY CONTIGUOUS memory is not the remedy:
+// with hipDeviceMallocContiguous every handle runs at 200-224 us, whatever the plane stride.  The request stays available for
+// experiments (GPF_CONTIGUOUS=1); the default is the ordinary allocation, and plan_placement picks among several of them.
+static hipError_t field_malloc(void** p, size_t bytes) {
+    static const bool on = std::getenv("GPF_CONTIGUOUS") && std::atoi(std::getenv("GPF_CONTIGUOUS")) == 1;
+    if (on && bytes >= (32u << 20)) {
+        if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous) == hipSuccess) return hipSuccess;
+        (void)hipGetLastError();
+    }
+    return hipMalloc(p, bytes);
+}
+
 extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
     if (!cfg || !out) return fail(GPF_ERR_INVALID, "gpf_create: null argument");
     if (cfg->Nx < 1 || cfg->Ny < 1) return fail(GPF_ERR_INVALID, "gpf_create: Nx, Ny must be >= 1");
@@ -257,10 +271,10 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
     } while (0)
     h->field_bytes = (3 * plane_b + PLANE_PAD_BYTES + 255) & ~(size_t)255;
     for (int b = 0; b < 2; ++b) {
-        HIP_TRY_C(hipMalloc(&h->q[b], h->field_bytes));
+        HIP_TRY_C(field_malloc((void**)&h->q[b], h->field_bytes));
         HIP_TRY_C(hipMemset(h->q[b], 0, h->field_bytes));
     }
-    HIP_TRY_C(hipMalloc(&h->topo, h->field_bytes));
+    HIP_TRY_C(field_malloc((void**)&h->topo, h->field_bytes));
     HIP_TRY_C(hipMemset(h->topo, 0, h->field_bytes));
     const size_t g1n = (size_t)3 * L.pitch + (size_t)3 * (L.Nx + 2);
     HIP_TRY_C(hipMalloc(&h->g1, g1n * sizeof(double)));
@@ -787,8 +801,8 @@ static int plan_placement(gpf_handle* h, int D, std::string& note) {
     cands.push_back(cur);
     for (int k = 1; k < tries; ++k) {
         Cand c = {{nullptr, nullptr}, nullptr, 0.f};
-        if (hipMalloc(&c.q[0], h->field_bytes) != hipSuccess || hipMalloc(&c.q[1], h->field_bytes) != hipSuccess ||
-            hipMalloc(&c.topo, h->field_bytes) != hipSuccess) {
+        if (field_malloc((void**)&c.q[0], h->field_bytes) != hipSuccess || field_malloc((void**)&c.q[1], h->field_bytes) != hipSuccess ||
+            field_malloc((void**)&c.topo, h->field_bytes) != hipSuccess) {
             for (void* p : {(void*)c.q[0], (void*)c.q[1], (void*)c.topo}) if (p) hipFree(p);
             (void)hipGetLastError();
             break;
