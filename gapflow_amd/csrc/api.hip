@@ -833,7 +833,7 @@ static int plan_placement(gpf_handle* h, int D, std::string& note) {
 // waves per SIMD and indifferent to the store policy, the 2-D-gap kernel 6 % faster with one wave per SIMD AND non-temporal
 // stores, 4 % with two waves and plain ones; round 2's runs on other boxes favoured one wave per SIMD for both), so grids of a
 // million cells and more TIME the candidates once, on their own data (plan_trial: ~8 ms per handle), and keep the fastest.
-// Smaller grids, slabs and GPF_PLAN_TUNE=0 take the rule of thumb; GPF_CHUNKS / GPF_NT_STORES pin a choice (A/B runs).
+// Smaller grids and GPF_PLAN_TUNE=0 take the rule of thumb; GPF_CHUNKS / GPF_NT_STORES pin a choice (A/B runs).
 static int plan_step2(gpf_handle* h, int D) {
     if (h->plan2_valid) return GPF_OK;
     const Layout& L = h->L;
@@ -858,8 +858,8 @@ static int plan_step2(gpf_handle* h, int D) {
     bool nt = nt_possible;
     if (env_chunks && std::atoi(env_chunks) > 0) nchunks = std::atoi(env_chunks);
     if (env_nt) nt = std::atoi(env_nt) != 0;
-    const bool slab = h->E.halo[0] || h->E.halo[1];
-    const bool tune = !(env_tune && std::atoi(env_tune) == 0) && !slab && !h->split_edges && h->pre_run_done && (long long)L.Nx * L.Ny >= (1ll << 20) &&
+    // (a slab tunes like any other handle: the trial launches commit into the scratch state and send nothing)
+    const bool tune = !(env_tune && std::atoi(env_tune) == 0) && !h->split_edges && h->pre_run_done && (long long)L.Nx * L.Ny >= (1ll << 20) &&
                       one_per_simd >= 1 && L.Nx / one_per_simd >= 16 && !(env_chunks && env_nt);
     if (!tune) {
         GPF_TRY(plan_apply(h, nchunks, nt));
