@@ -777,54 +777,123 @@ static int plan_trial(gpf_handle* h, int D, float* us) {
     return GPF_OK;
 }
 
-// WHERE the fields lie in device memory.  The same kernel on the same device runs at two speeds -- e.g. 167 or 183 us at 4096^2 --
-// depending on which physical pages the allocator happened to hand out for the two state buffers: twelve identical handles of one
-// process, with identical virtual layouts, split 1 : 11 in one run and 5 : 7 in another, each handle keeping its speed for as long
-// as it lives (tools/ab_inprocess.py, profiles/r03_placement/).  Offsets between the buffers, one allocation instead of three and
-// the plane stride were scanned without finding the rule (a padded plane stride moves the slow level by 5 %, not the fast one), so
-// large grids do what the plan does: they TRY.  A few more triples of buffers are allocated -- all held until the end, or the
-// allocator would hand the same pages out again --, the fields are copied, the step is timed on each, the fastest triple becomes
-// the handle's memory and the others are freed.  GPF_PLACEMENT_TRIES sets the number of candidates (default 6, 0 or 1: none).
+// WHERE the fields lie in device memory.  The same kernel on the same device runs at two speeds -- e.g. 167 or 183 us at 4096^2,
+// 234 or 275 us with the gap planes -- depending on which physical pages the allocator happened to hand out for the buffers it
+// reads and writes: twelve identical handles of one process, with identical virtual layouts, split 1 : 11 in one run and 5 : 7 in
+// another, each handle keeping its speed for as long as it lives (tools/ab_inprocess.py, profiles/r03_placement/).  Offsets between
+// the buffers, one allocation instead of three and the plane stride were scanned without finding the rule, and physically
+// contiguous memory is the slowest of all, so large grids do what the plan does: they TRY.  A few spare buffers join the handle's own
+// in a pool.  Most of what distinguishes the buffers shows when they are WRITTEN (profiles/r03_placement/pair_matrices.txt: one
+// column of the read x written matrix stands out, not one row), so the step is first timed writing each buffer of the pool in
+// turn; then, for the best four, for every ordered (read, written) pair -- a step reads one state buffer and writes the other, the
+// next one the other way round, so a pair's figure is the sum of both directions.  The best pair becomes the handle's memory, then
+// (kernels that read the gap planes) the best home among a few of the remaining buffers for those; the rest is freed.  With S spares:
+// S + 2 + 12 trials of 7 launches and S + 1 buffers of transient memory (whole triples, as first tried: S trials for 3 S buffers).
+// GPF_PLACEMENT_TRIES sets S (default 10; 0: keep what hipMalloc gave); GPF_PLACEMENT_PRINT=1 prints the figures.
 static int plan_placement(gpf_handle* h, int D, std::string& note) {
-    int tries = 6;
-    if (const char* s = std::getenv("GPF_PLACEMENT_TRIES")) tries = std::atoi(s);
+    int spares = 10;
+    if (const char* s = std::getenv("GPF_PLACEMENT_TRIES")) spares = std::atoi(s);
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    while (tries > 1 && (size_t)(tries - 1) * 3 * h->field_bytes + (2ull << 30) > free_b) --tries;
-    if (tries <= 1) return GPF_OK;
+    while (spares > 0 && (size_t)(spares + 1) * h->field_bytes + (2ull << 30) > free_b) --spares;
+    if (spares <= 0) return GPF_OK;
+    const bool print = std::getenv("GPF_PLACEMENT_PRINT") && std::atoi(std::getenv("GPF_PLACEMENT_PRINT")) != 0;
     int par = 0;
     GPF_TRY(current_parity(h, &par));
-    struct Cand { double* q[2]; double* topo; float us; };
-    std::vector<Cand> cands;
-    Cand cur = {{h->q[0], h->q[1]}, h->topo, 0.f};
-    GPF_TRY(plan_trial(h, D, &cur.us));
-    cands.push_back(cur);
-    for (int k = 1; k < tries; ++k) {
-        Cand c = {{nullptr, nullptr}, nullptr, 0.f};
-        if (field_malloc((void**)&c.q[0], h->field_bytes) != hipSuccess || field_malloc((void**)&c.q[1], h->field_bytes) != hipSuccess ||
-            field_malloc((void**)&c.topo, h->field_bytes) != hipSuccess) {
-            for (void* p : {(void*)c.q[0], (void*)c.q[1], (void*)c.topo}) if (p) hipFree(p);
-            (void)hipGetLastError();
-            break;
+    const bool planes = topo_mode_of(h) == 0;               // the kernel reads h->topo (otherwise the gap travels as a line)
+    double* master = nullptr;                                // the current state, never a candidate
+    if (field_malloc((void**)&master, h->field_bytes) != hipSuccess) { (void)hipGetLastError(); return GPF_OK; }
+    std::vector<double*> pool = {h->q[par], h->q[par ^ 1]};
+    for (int k = 0; k < spares; ++k) {
+        double* b = nullptr;
+        if (field_malloc((void**)&b, h->field_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        HIP_TRY(hipMemsetAsync(b, 0, h->field_bytes, h->stream));
+        pool.push_back(b);
+    }
+    const int n = (int)pool.size();
+    HIP_TRY(hipMemcpyAsync(master, h->q[par], h->field_bytes, hipMemcpyDeviceToDevice, h->stream));
+    std::vector<char> holds_state(n, 0);
+    holds_state[0] = 1;
+    auto trial = [&](int i, int j, float* us) -> int {      // read pool[i], write pool[j]
+        if (!holds_state[i]) {
+            HIP_TRY(hipMemcpyAsync(pool[i], master, h->field_bytes, hipMemcpyDeviceToDevice, h->stream));
+            holds_state[i] = 1;
         }
-        HIP_TRY(hipMemcpyAsync(c.q[par], cur.q[par], h->field_bytes, hipMemcpyDeviceToDevice, h->stream));
-        HIP_TRY(hipMemsetAsync(c.q[par ^ 1], 0, h->field_bytes, h->stream));
-        HIP_TRY(hipMemcpyAsync(c.topo, cur.topo, h->field_bytes, hipMemcpyDeviceToDevice, h->stream));
-        h->q[0] = c.q[0]; h->q[1] = c.q[1]; h->topo = c.topo;
-        GPF_TRY(plan_trial(h, D, &c.us));
-        cands.push_back(c);
+        holds_state[j] = 0;
+        h->q[par] = pool[i]; h->q[par ^ 1] = pool[j];
+        return plan_trial(h, D, us);
+    };
+    // phase 1: every buffer as the one WRITTEN (the state read from the handle's own buffer; that one is written reading its twin) --
+    // most of what distinguishes the buffers shows there (profiles/r03_placement/pair_matrices.txt)
+    std::vector<float> w(n, 0.f);
+    for (int k = 1; k < n; ++k) GPF_TRY(trial(0, k, &w[k]));
+    GPF_TRY(trial(1, 0, &w[0]));
+    std::vector<int> order(n);
+    for (int k = 0; k < n; ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return w[x] < w[y]; });
+    // phase 2: the best few, every ordered pair
+    const int m = std::min(n, 4);
+    std::vector<float> t((size_t)m * m, 0.f);
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j)
+            if (i != j) GPF_TRY(trial(order[i], order[j], &t[(size_t)i * m + j]));
+    int bi = order[0], bj = order[1];
+    float best = t[1] + t[m], worst = best;
+    for (int i = 0; i < m; ++i)
+        for (int j = i + 1; j < m; ++j) {
+            const float both = t[(size_t)i * m + j] + t[(size_t)j * m + i];
+            if (both < best) { best = both; bi = order[i]; bj = order[j]; }
+            worst = std::max(worst, both);
+        }
+    if (print) {
+        std::fprintf(stderr, "[gpf] placement: us per step writing each buffer (0, 1: the handle's own):");
+        for (int k = 0; k < n; ++k) std::fprintf(stderr, " %.1f", w[k]);
+        std::fprintf(stderr, "\n[gpf] placement: the best %d, row = buffer read, column = buffer written\n", m);
+        for (int i = 0; i < m; ++i) {
+            std::fprintf(stderr, "[gpf]   #%-2d %p", order[i], (void*)pool[order[i]]);
+            for (int j = 0; j < m; ++j) std::fprintf(stderr, " %6.1f", t[(size_t)i * m + j]);
+            std::fprintf(stderr, "\n");
+        }
     }
-    size_t best = 0;
-    for (size_t k = 1; k < cands.size(); ++k) if (cands[k].us < cands[best].us) best = k;
+    char buf[200];
+    std::snprintf(buf, sizeof buf, " placement: %d buffers, written %.0f .. %.0f us, pair kept %.0f, hipMalloc's own %.0f", n,
+                  *std::min_element(w.begin(), w.end()), *std::max_element(w.begin(), w.end()), 0.5f * best, 0.5f * (w[0] + w[1]));
+    note = buf;
+    // the best pair, the state in its first member
+    float us = 0.f;
+    GPF_TRY(trial(bi, bj, &us));
+    std::vector<double*> rest;
+    for (int k = 0; k < n; ++k) if (k != bi && k != bj) rest.push_back(pool[k]);
+    if (planes) {
+        // the gap planes: their present home or one of the buffers left over (both directions of the step timed for each)
+        double* const own = h->topo;
+        double* best_home = own;
+        float best_t = 0.f;
+        std::string seen;
+        for (size_t k = 0; k <= std::min<size_t>(rest.size(), 3); ++k) {
+            double* cand = k == 0 ? own : rest[k - 1];
+            if (cand != own) HIP_TRY(hipMemcpyAsync(cand, own, h->field_bytes, hipMemcpyDeviceToDevice, h->stream));
+            h->topo = cand;
+            float a = 0.f, b = 0.f;
+            GPF_TRY(trial(bi, bj, &a));
+            GPF_TRY(trial(bj, bi, &b));
+            std::snprintf(buf, sizeof buf, " %.0f", 0.5f * (a + b));
+            seen += buf;
+            if (k == 0 || a + b < best_t) { best_t = a + b; best_home = cand; }
+        }
+        note += "; gap planes:" + seen;
+        if (best_home != own) {
+            HIP_TRY(hipMemcpyAsync(best_home, own, h->field_bytes, hipMemcpyDeviceToDevice, h->stream));    // (a later trial wrote nothing here, but be plain)
+            rest.erase(std::find(rest.begin(), rest.end(), best_home));
+            rest.push_back(own);
+        }
+        h->topo = best_home;
+        GPF_TRY(trial(bi, bj, &us));                        // leaves the state in pool[bi] = q[par]
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));
-    note = " placement, us:";
-    for (size_t k = 0; k < cands.size(); ++k) {
-        char buf[24];
-        std::snprintf(buf, sizeof buf, " %.0f", cands[k].us);
-        note += buf;
-        if (k != best) { hipFree(cands[k].q[0]); hipFree(cands[k].q[1]); hipFree(cands[k].topo); }
-    }
-    h->q[0] = cands[best].q[0]; h->q[1] = cands[best].q[1]; h->topo = cands[best].topo;
+    for (double* b : rest) hipFree(b);
+    hipFree(master);
+    h->q[par] = pool[bi]; h->q[par ^ 1] = pool[bj];
     return GPF_OK;
 }
 

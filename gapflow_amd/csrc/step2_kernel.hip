@@ -303,10 +303,36 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
     // wait until row r has landed: exactly AHEAD row requests (NL loads each) have been issued after it
     constexpr bool HEAVY = Step2Weight<EOS, HAS_LS, PIEZO>::heavy;
     constexpr int AHEAD_ROWS = PIEZO ? 1 : ((TOPO == 1 || TOPO == 3) ? (HEAVY ? 2 : GPF_K2_AHEAD_LINE) : GPF_K2_AHEAD);
-    auto arrive = [&](Raw& r) {
-        asm_wait3<AHEAD_ROWS * NL>(r.q[0], r.q[1], r.q[2]);
-        if (TOPO == 0) asm_wait3<AHEAD_ROWS * NL>(r.t[0], r.t[1], r.t[2]);
-        if (HAS_LS) asm_wait1<AHEAD_ROWS * NL>(r.ls[0]);
+    // The stores of the rows finished in between are vector-memory operations too and sit in the same counter, in issue order:
+    // once the march is AHEAD rows past its first output row, every loop body since row r's request has issued three of them
+    // (a wave with at least one output lane takes at least one of the three store branches below), so the exact number of younger
+    // operations is AHEAD * (NL + 3).  Waiting for AHEAD * NL there would ask for the rows r+1, r+2 .. as well -- half the
+    // requests in flight for nothing.  (gfx9 keeps loads and stores in ONE in-order counter; hipcc's own waits rely on that too.)
+#ifndef GPF_K2_COUNT_STORES
+#define GPF_K2_COUNT_STORES 1
+#endif
+    const bool stores_every_row = GPF_K2_COUNT_STORES && __builtin_amdgcn_ballot_w64(out0 || out1) != 0ull;
+    auto arrive = [&](Raw& r, const int n) {
+        constexpr int LOOSE = AHEAD_ROWS * NL, EXACT = AHEAD_ROWS * (NL + 3);
+        static_assert(EXACT <= 63, "vmcnt is a 6-bit counter");
+        // ONE asm statement names every destination of the row (two statements in an if / else make hipcc join their "+v" results
+        // with register copies -- of registers whose loads are in flight: tools/audit_step_isa.py); the choice is a branch inside it
+        // (readfirstlane: an "s" operand is handed over as it is, and hipcc keeps this wave-uniform value in a VGPR in some variants)
+        const int exact = __builtin_amdgcn_readfirstlane((stores_every_row && n > n_first + AHEAD_ROWS) ? 1 : 0);
+#define GPF_WAIT_ROW "s_cmp_lg_u32 %[ex], 0\n\ts_cbranch_scc1 .Lgpf_exact_%=\n\ts_waitcnt vmcnt(%[loose])\n.Lgpf_exact_%=:\n\ts_waitcnt vmcnt(%[exact])"
+        if constexpr (TOPO == 0 && HAS_LS)
+            asm volatile(GPF_WAIT_ROW : "+v"(r.q[0]), "+v"(r.q[1]), "+v"(r.q[2]), "+v"(r.t[0]), "+v"(r.t[1]), "+v"(r.t[2]), "+v"(r.ls[0])
+                         : [ex] "s"(exact), [loose] "n"(LOOSE), [exact] "n"(EXACT) : "memory", "scc");
+        else if constexpr (TOPO == 0)
+            asm volatile(GPF_WAIT_ROW : "+v"(r.q[0]), "+v"(r.q[1]), "+v"(r.q[2]), "+v"(r.t[0]), "+v"(r.t[1]), "+v"(r.t[2])
+                         : [ex] "s"(exact), [loose] "n"(LOOSE), [exact] "n"(EXACT) : "memory", "scc");
+        else if constexpr (HAS_LS)
+            asm volatile(GPF_WAIT_ROW : "+v"(r.q[0]), "+v"(r.q[1]), "+v"(r.q[2]), "+v"(r.ls[0])
+                         : [ex] "s"(exact), [loose] "n"(LOOSE), [exact] "n"(EXACT) : "memory", "scc");
+        else
+            asm volatile(GPF_WAIT_ROW : "+v"(r.q[0]), "+v"(r.q[1]), "+v"(r.q[2])
+                         : [ex] "s"(exact), [loose] "n"(LOOSE), [exact] "n"(EXACT) : "memory", "scc");
+#undef GPF_WAIT_ROW
     };
     auto unpack = [&](const Raw& r, Row2& o) {
         o.rho[0] = D > 0 ? r.q[0].x : r.q[0].y; o.rho[1] = D > 0 ? r.q[0].y : r.q[0].x;
@@ -426,7 +452,7 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
         // (beyond the chunk's last row `issue` sends a dummy request: the number of loads in flight behind `raw` is the
         // same in every iteration, and the wait needs no case distinction)
         issue(n + AHEAD, spare);
-        arrive(raw);
+        arrive(raw, n);
         Row2 cur;
         unpack(raw, cur);
         const bool first = (n == n_first - 1);
@@ -518,8 +544,12 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
                     dpair* p = reinterpret_cast<dpair*>(reinterpret_cast<char*>(rowp) + lane_bytes);
 #if GPF_K2_NT & 2
                     // (only where the step's working set exceeds the 256-MiB Infinity Cache: a small grid -- one rank's slab of the
-                    // 8-GPU run, 2 x 50 MB -- finds its previous output still on the die, and bypassing it costs 5 %)
-                    if (nt_stores) __builtin_nontemporal_store(v, p); else *p = v;
+                    // 8-GPU run, 2 x 50 MB -- finds its previous output still on the die.)  The hinted store is written in asm:
+                    // given `if (nt) __builtin_nontemporal_store(v, p); else *p = v;` hipcc sinks the two stores into one and
+                    // drops the hint -- the library of the first half of round 3 held no `nt` store at all (llvm-objdump).
+                    // s_nop: a store of more than 8 bytes must not be followed at once by a write of its data registers.
+                    if (nt_stores) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" :: "v"(p), "v"(v) : "memory");
+                    else *p = v;
 #else
                     *p = v;
 #endif

@@ -58,6 +58,7 @@ def main():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        print(f'{name}: {prob._lib.gpf_plan_note(prob._h).decode()}', flush=True)
         variants.append((name, prob, []))
     kt, tt = C.c_double(0), C.c_double(0)
     for b in range(batches):
