@@ -974,7 +974,10 @@ static int plan_step2(gpf_handle* h, int D) {
 
 extern "C" const char* gpf_plan_note(gpf_handle* h) { return h ? h->plan2_note : ""; }
 
-constexpr int SLAB_COMMIT_BLOCKS = 24;     // k_begin_slab without stage-1 work: a 6-row copy and the commit
+#ifndef GPF_SLAB_COMMIT_BLOCKS
+#define GPF_SLAB_COMMIT_BLOCKS 24
+#endif
+constexpr int SLAB_COMMIT_BLOCKS = GPF_SLAB_COMMIT_BLOCKS;     // k_begin_slab without stage-1 work: a 6-row copy and the commit
 
 static P2PArgs p2p_args(gpf_handle* h, bool on) {
     P2PArgs c;
