@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -135,7 +137,8 @@ struct gpf_handle {
     bool plan2_valid = false;
     bool nt_stores2 = false;                // k_step2 writes q with the non-temporal hint (plan_step2)
     StepState* st_trial = nullptr;          // plan_step2's timing launches commit into this copy of the run state
-    char plan2_note[256] = "";              // how the plan was arrived at (gpf_plan_note)
+    double* plan_master = nullptr;          // copy of the current state while plan_step2 runs its trials
+    char plan2_note[400] = "";              // how the plan was arrived at (gpf_plan_note)
 };
 
 static int enter(gpf_handle* h, bool reads_only) {
@@ -202,18 +205,145 @@ static int ensure_stage(gpf_handle* h, size_t doubles) {
     return GPF_OK;
 }
 
-// The buffers the step kernel streams.  What makes identical handles run at 167 or 183 us (profiles/r03_placement/) shows in the
-// translation counters -- the fast handles have the fewest translations in flight in the CUs' TLBs (TCP_CLIENT_UTCL1_INFLIGHT
-// 1.1e9 against 1.7e9 per launch) and the lowest read latency -- but asking for PHYSICALLY CONTIGUOUS memory is not the remedy:
-// with hipDeviceMallocContiguous every handle runs at 200-224 us, whatever the plane stride.  The request stays available for
-// experiments (GPF_CONTIGUOUS=1); the default is the ordinary allocation, and plan_placement picks among several of them.
+// The buffers the step kernel streams: q[0], q[1], the gap planes, and the candidates plan_placement tries in their place.
+// hipMalloc backs a buffer of this size with a few large, naturally aligned blocks of device memory, so the streams of a launch --
+// rows of three planes 128 MiB-and-a-bit apart, read from one buffer and written to the other at the same offsets -- keep a fixed
+// relation in every address bit above the block offset, and on most boxes of the pool that relation is a bad one: 185-190 us per
+// step where 160-170 are possible, 275 instead of 235 with the gap planes (profiles/r03_placement/scattered_pages.txt; asking for
+// physically contiguous memory makes it worse still: 200-224 us).  So a large field is ONE range of virtual addresses backed by
+// separate physical allocations of 16 MiB mapped in a shuffled order (HIP's virtual memory management): no two streams keep a
+// fixed distance for long.  GPF_SCATTER_MB sets the size of the pieces (0: plain hipMalloc; 2 MiB pieces lose a little to the
+// TLBs, 64 MiB and more leave too few pieces to shuffle); GPF_CONTIGUOUS=1 asks for contiguous memory instead (experiments).
+struct ScatteredField { size_t bytes, part; std::vector<hipMemGenericAllocationHandle_t> parts; };
+static std::mutex& scattered_lock() { static std::mutex m; return m; }
+static std::map<void*, ScatteredField>& scattered_fields() { static std::map<void*, ScatteredField> m; return m; }
+static hipError_t field_malloc_scattered(void** p, size_t bytes, size_t part) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0) return hipErrorNotSupported;
+    part = (part + gran - 1) / gran * gran;
+    const size_t n = (bytes + part - 1) / part, total = n * part;
+    void* va = nullptr;
+    if (hipMemAddressReserve(&va, total, 0, nullptr, 0) != hipSuccess) return hipErrorOutOfMemory;
+    {   // a reservation must not overlap a live one (seen? then say so and leave the virtual-memory path alone)
+        std::lock_guard<std::mutex> g(scattered_lock());
+        for (auto& kv : scattered_fields()) {
+            const char* a0 = (const char*)kv.first; const char* a1 = a0 + kv.second.bytes;
+            if ((const char*)va < a1 && a0 < (const char*)va + total) {
+                std::fprintf(stderr, "[gpf] field_malloc: hipMemAddressReserve returned %p + %zu inside the live range %p + %zu\n", va, total, kv.first, kv.second.bytes);
+                return hipErrorOutOfMemory;
+            }
+        }
+    }
+    ScatteredField f;
+    f.bytes = total; f.part = part;
+    size_t mapped = 0;
+    auto undo = [&]() {
+        for (size_t k = 0; k < mapped; ++k) (void)hipMemUnmap((char*)va + k * part, part);
+        for (auto& hnd : f.parts) (void)hipMemRelease(hnd);
+        (void)hipGetLastError();                             // (the address range stays reserved: see field_free)
+        return hipErrorOutOfMemory;
+    };
+    for (size_t k = 0; k < n; ++k) {
+        hipMemGenericAllocationHandle_t hnd;
+        if (hipMemCreate(&hnd, part, &prop, 0) != hipSuccess) return undo();
+        f.parts.push_back(hnd);
+    }
+    std::vector<size_t> order(n);
+    for (size_t k = 0; k < n; ++k) order[k] = k;
+    unsigned long long x = 0x9e3779b97f4a7c15ull ^ (unsigned long long)(uintptr_t)va;
+    for (size_t k = n - 1; k > 0; --k) {                     // Fisher-Yates with a xorshift generator
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        std::swap(order[k], order[x % (k + 1)]);
+    }
+    for (size_t k = 0; k < n; ++k) {
+        if (hipMemMap((char*)va + k * part, part, 0, f.parts[order[k]], 0) != hipSuccess) return undo();
+        ++mapped;
+    }
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemSetAccess(va, total, &acc, 1) != hipSuccess) return undo();
+    {
+        std::lock_guard<std::mutex> g(scattered_lock());
+        scattered_fields()[va] = f;
+    }
+    *p = va;
+    return hipSuccess;
+}
 static hipError_t field_malloc(void** p, size_t bytes) {
-    static const bool on = std::getenv("GPF_CONTIGUOUS") && std::atoi(std::getenv("GPF_CONTIGUOUS")) == 1;
-    if (on && bytes >= (32u << 20)) {
+    static const bool contiguous = std::getenv("GPF_CONTIGUOUS") && std::atoi(std::getenv("GPF_CONTIGUOUS")) == 1;
+    const int scatter_mb = std::getenv("GPF_SCATTER_MB") ? std::atoi(std::getenv("GPF_SCATTER_MB")) : 16;      // (read per call: A/B handles in one process)
+    if (contiguous && bytes >= (32u << 20)) {
         if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous) == hipSuccess) return hipSuccess;
+        (void)hipGetLastError();
+    } else if (scatter_mb > 0 && bytes >= ((size_t)scatter_mb << 22)) {          // at least four pieces
+        if (field_malloc_scattered(p, bytes, (size_t)scatter_mb << 20) == hipSuccess) return hipSuccess;
         (void)hipGetLastError();
     }
     return hipMalloc(p, bytes);
+}
+static void field_free(void* p) {
+    if (!p) return;
+    ScatteredField f;
+    {
+        std::lock_guard<std::mutex> g(scattered_lock());
+        auto it = scattered_fields().find(p);
+        if (it == scattered_fields().end()) { (void)hipFree(p); return; }
+        f = it->second;
+        scattered_fields().erase(it);
+    }
+    // The pieces are unmapped and released; the ADDRESS RANGE is not given back.  On this ROCm (7.0 / 7.2) a range that has been
+    // freed and is reserved again reads and writes the wrong memory: of four rounds of "three fields are created, eleven are created,
+    // filled, checked and nine of them freed", 11 of 94 read-backs found a damaged buffer with hipMemAddressFree and none without it,
+    // whichever way the unmapping was done (tools/vmm_probe.hip; here it cost the second of two handles its state:
+    // tests/test_gpu_fullsize.py, flip symmetry).  A reservation costs address space only -- 128 TiB of it per process.
+    int bad = 0;
+    for (size_t k = 0; k < f.parts.size(); ++k) bad += hipMemUnmap((char*)p + k * f.part, f.part) != hipSuccess;
+    for (auto& hnd : f.parts) bad += hipMemRelease(hnd) != hipSuccess;
+    if (bad) { (void)hipGetLastError(); std::fprintf(stderr, "[gpf] field_free: %d call(s) of the virtual-memory API failed for %p\n", bad, p); }
+}
+
+// Copies and fills of whole fields run as kernels on the handle's stream: a field may be a range of virtual addresses made of many
+// separately mapped pieces (field_malloc), and what hipMemcpyAsync / hipMemsetAsync do with such a range across its pieces -- and in
+// which order relative to the stream -- is the runtime's business (tests/test_gpu_fullsize.py lost time steps to a copy that landed
+// after the launches queued behind it).
+__global__ void k_field_copy(double2* __restrict__ dst, const double2* __restrict__ src, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ void k_field_zero(double2* __restrict__ dst, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = double2{0.0, 0.0};
+}
+static int field_copy(hipStream_t s, void* dst, const void* src, size_t bytes) {
+    hipLaunchKernelGGL(k_field_copy, dim3(2048), dim3(256), 0, s, (double2*)dst, (const double2*)src, bytes / sizeof(double2));
+    HIP_TRY(hipGetLastError());
+    return GPF_OK;
+}
+__global__ void k_field_xor(const unsigned long long* __restrict__ p, size_t n, unsigned long long* out) {
+    unsigned long long x = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x ^= p[i] * (i | 1);
+    atomicXor(out, x);
+}
+// (diagnostics: GPF_PLACEMENT_PRINT=2 prints a checksum of the state at every stage of the tuner)
+static unsigned long long field_checksum(hipStream_t s, const void* p, size_t bytes) {
+    unsigned long long* d = nullptr; unsigned long long h = 0;
+    if (hipMalloc(&d, 8) != hipSuccess) return 0;
+    (void)hipMemsetAsync(d, 0, 8, s);
+    hipLaunchKernelGGL(k_field_xor, dim3(1024), dim3(256), 0, s, (const unsigned long long*)p, bytes / 8, d);
+    (void)hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(d);
+    return h;
+}
+static int field_zero(hipStream_t s, void* dst, size_t bytes) {
+    hipLaunchKernelGGL(k_field_zero, dim3(2048), dim3(256), 0, s, (double2*)dst, bytes / sizeof(double2));
+    HIP_TRY(hipGetLastError());
+    return GPF_OK;
 }
 
 extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
@@ -273,10 +403,11 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
     h->field_bytes = (3 * plane_b + PLANE_PAD_BYTES + 255) & ~(size_t)255;
     for (int b = 0; b < 2; ++b) {
         HIP_TRY_C(field_malloc((void**)&h->q[b], h->field_bytes));
-        HIP_TRY_C(hipMemset(h->q[b], 0, h->field_bytes));
+        if (field_zero(0, h->q[b], h->field_bytes) != GPF_OK) { gpf_destroy(h); return GPF_ERR_HIP; }
     }
     HIP_TRY_C(field_malloc((void**)&h->topo, h->field_bytes));
-    HIP_TRY_C(hipMemset(h->topo, 0, h->field_bytes));
+    if (field_zero(0, h->topo, h->field_bytes) != GPF_OK) { gpf_destroy(h); return GPF_ERR_HIP; }
+    HIP_TRY_C(hipDeviceSynchronize());
     const size_t g1n = (size_t)3 * L.pitch + (size_t)3 * (L.Nx + 2);
     HIP_TRY_C(hipMalloc(&h->g1, g1n * sizeof(double)));
     HIP_TRY_C(hipMemset(h->g1, 0, g1n * sizeof(double)));
@@ -299,7 +430,8 @@ extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
 extern "C" int gpf_destroy(gpf_handle* h) {
     if (!h) return GPF_OK;
     hipSetDevice(h->cfg.device);
-    void* ptrs[] = {h->q[0], h->q[1], h->topo, h->topo_line, h->Ls, h->g1, h->seam, h->halo, h->beyond, h->st, h->partials, h->arrive, h->block_partials, h->spart,
+    for (void* p : {(void*)h->q[0], (void*)h->q[1], (void*)h->topo, (void*)h->plan_master}) field_free(p);
+    void* ptrs[] = {h->topo_line, h->Ls, h->g1, h->seam, h->halo, h->beyond, h->st, h->partials, h->arrive, h->block_partials, h->spart,
                     h->log, h->stage, h->fields, h->work, h->st_trial, h->gpvar, h->gp_state_mean, h->gpscratch, h->gptile,
                     h->gp[0].Z, h->gp[0].alpha, h->gp[0].L, h->gp[1].Z, h->gp[1].alpha, h->gp[1].L,
                     h->gp[2].Z, h->gp[2].alpha, h->gp[2].L, h->gp[0].Linv, h->gp[1].Linv, h->gp[2].Linv, h->gp[0].W, h->gp[1].W, h->gp[2].W};
@@ -750,10 +882,16 @@ static void fill_step2_args(gpf_handle* h, Step2Args& a2, int D, int honor_stop,
 
 // Mean duration (us) of the fused step with the plan in force, on the handle's own field: the launches read the current state and
 // write the OTHER buffer (dead until the next step overwrites it) and commit into a copy of the run state, which is reset before
-// every launch -- nothing the solver will read changes.
-static int plan_trial(gpf_handle* h, int D, float* us, int reps = 6) {
+// every launch -- nothing the solver will read changes.  `both`: every other launch runs the other way round, reading what the
+// launch before has written and overwriting the current state (a step reads q[0] and writes q[1], the next one q[1] and q[0], and
+// the two can differ by 10 %: it is the buffer WRITTEN that counts); the state is restored from h->plan_master afterwards.
+static int plan_trial(gpf_handle* h, int D, float* us, int reps = 6, bool both = false) {
+    static const int parity_value[2] = {0, 1};
     if (!h->st_trial) HIP_TRY(hipMalloc(&h->st_trial, sizeof(StepState)));
     h->prev_state_valid = false;            // the launches below overwrite the other buffer
+    both = both && h->plan_master != nullptr;
+    int par = 0;
+    if (both) GPF_TRY(current_parity(h, &par));
     Step2Args a2;
     fill_step2_args(h, a2, D, 0, 0, nullptr, false);
     a2.st = h->st_trial; a2.log = nullptr;
@@ -763,6 +901,8 @@ static int plan_trial(gpf_handle* h, int D, float* us, int reps = 6) {
     float total = 0.f;
     for (int r = -1; r < reps; ++r) {       // r = -1: warm-up, not timed
         HIP_TRY(hipMemcpyAsync(h->st_trial, h->st, sizeof(StepState), hipMemcpyDeviceToDevice, h->stream));
+        if (both && ((r + 1) & 1))
+            HIP_TRY(hipMemcpyAsync(&h->st_trial->parity, &parity_value[par ^ 1], sizeof(int), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipEventRecord(e0, h->stream));
         hipLaunchKernelGGL(k2, dim3(h->nblocks2), dim3(256), 0, h->stream, a2, h->P);
         HIP_TRY(hipEventRecord(e1, h->stream));
@@ -772,6 +912,7 @@ static int plan_trial(gpf_handle* h, int D, float* us, int reps = 6) {
         if (r >= 0) total += ms;
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
+    if (both) GPF_TRY(field_copy(h->stream, h->q[par], h->plan_master, h->field_bytes));
     HIP_TRY(hipGetLastError());
     *us = total / reps * 1e3f;
     return GPF_OK;
@@ -795,104 +936,96 @@ static int plan_placement(gpf_handle* h, int D, std::string& note) {
     if (const char* s = std::getenv("GPF_PLACEMENT_TRIES")) spares = std::atoi(s);
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    while (spares > 0 && (size_t)(spares + 1) * h->field_bytes + (2ull << 30) > free_b) --spares;
-    if (spares <= 0) return GPF_OK;
+    while (spares > 0 && (size_t)spares * h->field_bytes + (2ull << 30) > free_b) --spares;
+    if (spares <= 0 || !h->plan_master) return GPF_OK;
     const bool print = std::getenv("GPF_PLACEMENT_PRINT") && std::atoi(std::getenv("GPF_PLACEMENT_PRINT")) != 0;
     int par = 0;
     GPF_TRY(current_parity(h, &par));
     const bool planes = topo_mode_of(h) == 0;               // the kernel reads h->topo (otherwise the gap travels as a line)
-    double* master = nullptr;                                // the current state, never a candidate
-    if (field_malloc((void**)&master, h->field_bytes) != hipSuccess) { (void)hipGetLastError(); return GPF_OK; }
+    double* const master = h->plan_master;                  // the current state, never a candidate
     std::vector<double*> pool = {h->q[par], h->q[par ^ 1]};
     for (int k = 0; k < spares; ++k) {
         double* b = nullptr;
         if (field_malloc((void**)&b, h->field_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-        HIP_TRY(hipMemsetAsync(b, 0, h->field_bytes, h->stream));
+        GPF_TRY(field_zero(h->stream, b, h->field_bytes));
         pool.push_back(b);
     }
     const int n = (int)pool.size();
-    HIP_TRY(hipMemcpyAsync(master, h->q[par], h->field_bytes, hipMemcpyDeviceToDevice, h->stream));
     std::vector<char> holds_state(n, 0);
     holds_state[0] = 1;
-    auto trial = [&](int i, int j, float* us) -> int {      // read pool[i], write pool[j]
+    // read pool[i], write pool[j]; `both`: and the other way round in every other launch (plan_trial restores the state in pool[i])
+    auto trial = [&](int i, int j, float* us, bool both) -> int {
         if (!holds_state[i]) {
-            HIP_TRY(hipMemcpyAsync(pool[i], master, h->field_bytes, hipMemcpyDeviceToDevice, h->stream));
+            GPF_TRY(field_copy(h->stream, pool[i], master, h->field_bytes));
             holds_state[i] = 1;
         }
         holds_state[j] = 0;
         h->q[par] = pool[i]; h->q[par ^ 1] = pool[j];
-        return plan_trial(h, D, us);
+        return plan_trial(h, D, us, 6, both);
     };
     // phase 1: every buffer as the one WRITTEN (the state read from the handle's own buffer; that one is written reading its twin) --
     // most of what distinguishes the buffers shows there (profiles/r03_placement/pair_matrices.txt)
     std::vector<float> w(n, 0.f);
-    for (int k = 1; k < n; ++k) GPF_TRY(trial(0, k, &w[k]));
-    GPF_TRY(trial(1, 0, &w[0]));
+    for (int k = 1; k < n; ++k) GPF_TRY(trial(0, k, &w[k], false));
+    GPF_TRY(trial(1, 0, &w[0], false));
     std::vector<int> order(n);
     for (int k = 0; k < n; ++k) order[k] = k;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return w[x] < w[y]; });
-    // phase 2: the best few, every ordered pair
+    // phase 2: the pairs of the best few and the handle's own pair, both directions of the step in each trial
     const int m = std::min(n, 4);
-    std::vector<float> t((size_t)m * m, 0.f);
-    for (int i = 0; i < m; ++i)
-        for (int j = 0; j < m; ++j)
-            if (i != j) GPF_TRY(trial(order[i], order[j], &t[(size_t)i * m + j]));
-    int bi = order[0], bj = order[1];
-    float best = t[1] + t[m], worst = best;
+    float own_pair = 0.f;
+    GPF_TRY(trial(0, 1, &own_pair, true));
+    int bi = 0, bj = 1;
+    float best = own_pair, worst = own_pair;
+    std::string pairs;
     for (int i = 0; i < m; ++i)
         for (int j = i + 1; j < m; ++j) {
-            const float both = t[(size_t)i * m + j] + t[(size_t)j * m + i];
-            if (both < best) { best = both; bi = order[i]; bj = order[j]; }
-            worst = std::max(worst, both);
+            const int x = std::min(order[i], order[j]), y = std::max(order[i], order[j]);
+            if (x == 0 && y == 1) continue;
+            float t = 0.f;
+            GPF_TRY(trial(x, y, &t, true));
+            if (print) { char b2[40]; std::snprintf(b2, sizeof b2, " (%d,%d) %.1f", x, y, t); pairs += b2; }
+            if (t < best) { best = t; bi = x; bj = y; }
+            worst = std::max(worst, t);
         }
     if (print) {
         std::fprintf(stderr, "[gpf] placement: us per step writing each buffer (0, 1: the handle's own):");
         for (int k = 0; k < n; ++k) std::fprintf(stderr, " %.1f", w[k]);
-        std::fprintf(stderr, "\n[gpf] placement: the best %d, row = buffer read, column = buffer written\n", m);
-        for (int i = 0; i < m; ++i) {
-            std::fprintf(stderr, "[gpf]   #%-2d %p", order[i], (void*)pool[order[i]]);
-            for (int j = 0; j < m; ++j) std::fprintf(stderr, " %6.1f", t[(size_t)i * m + j]);
-            std::fprintf(stderr, "\n");
-        }
+        std::fprintf(stderr, "\n[gpf] placement: pairs, both directions: (0,1) %.1f%s\n", own_pair, pairs.c_str());
     }
     char buf[200];
-    std::snprintf(buf, sizeof buf, " placement: %d buffers, written %.0f .. %.0f us, pair kept %.0f, hipMalloc's own %.0f", n,
-                  *std::min_element(w.begin(), w.end()), *std::max_element(w.begin(), w.end()), 0.5f * best, 0.5f * (w[0] + w[1]));
+    std::snprintf(buf, sizeof buf, " placement: %d buffers, written %.0f .. %.0f us, pair kept %.0f, the handle's own %.0f", n,
+                  *std::min_element(w.begin(), w.end()), *std::max_element(w.begin(), w.end()), best, own_pair);
     note = buf;
-    // the best pair, the state in its first member
-    float us = 0.f;
-    GPF_TRY(trial(bi, bj, &us));
     std::vector<double*> rest;
     for (int k = 0; k < n; ++k) if (k != bi && k != bj) rest.push_back(pool[k]);
+    float us = 0.f;
     if (planes) {
-        // the gap planes: their present home or one of the buffers left over (both directions of the step timed for each)
+        // the gap planes: their present home or one of the buffers left over
         double* const own = h->topo;
         double* best_home = own;
         float best_t = 0.f;
         std::string seen;
         for (size_t k = 0; k <= std::min<size_t>(rest.size(), 3); ++k) {
             double* cand = k == 0 ? own : rest[k - 1];
-            if (cand != own) HIP_TRY(hipMemcpyAsync(cand, own, h->field_bytes, hipMemcpyDeviceToDevice, h->stream));
+            if (cand != own) GPF_TRY(field_copy(h->stream, cand, own, h->field_bytes));
             h->topo = cand;
-            float a = 0.f, b = 0.f;
-            GPF_TRY(trial(bi, bj, &a));
-            GPF_TRY(trial(bj, bi, &b));
-            std::snprintf(buf, sizeof buf, " %.0f", 0.5f * (a + b));
+            float t = 0.f;
+            GPF_TRY(trial(bi, bj, &t, true));
+            std::snprintf(buf, sizeof buf, " %.0f", t);
             seen += buf;
-            if (k == 0 || a + b < best_t) { best_t = a + b; best_home = cand; }
+            if (k == 0 || t < best_t) { best_t = t; best_home = cand; }
         }
         note += "; gap planes:" + seen;
         if (best_home != own) {
-            HIP_TRY(hipMemcpyAsync(best_home, own, h->field_bytes, hipMemcpyDeviceToDevice, h->stream));    // (a later trial wrote nothing here, but be plain)
             rest.erase(std::find(rest.begin(), rest.end(), best_home));
             rest.push_back(own);
         }
         h->topo = best_home;
-        GPF_TRY(trial(bi, bj, &us));                        // leaves the state in pool[bi] = q[par]
     }
+    GPF_TRY(trial(bi, bj, &us, true));                      // leaves the state in pool[bi] = q[par]
     HIP_TRY(hipStreamSynchronize(h->stream));
-    for (double* b : rest) hipFree(b);
-    hipFree(master);
+    for (double* b : rest) field_free(b);
     h->q[par] = pool[bi]; h->q[par ^ 1] = pool[bj];
     return GPF_OK;
 }
@@ -939,34 +1072,67 @@ static int plan_step2(gpf_handle* h, int D) {
     }
     std::string placement_note;
     GPF_TRY(plan_apply(h, nchunks, nt));
+    {   // a copy of the state: trials that run the step both ways overwrite it (plan_trial)
+        int par = 0;
+        GPF_TRY(current_parity(h, &par));
+        if (field_malloc((void**)&h->plan_master, h->field_bytes) == hipSuccess)
+            GPF_TRY(field_copy(h->stream, h->plan_master, h->q[par], h->field_bytes));
+        else { (void)hipGetLastError(); h->plan_master = nullptr; }
+    }
     {   // The trials come after an idle stretch (the host has just built the problem) and the device takes ~10 ms of load to reach its
         // running clocks: the first candidates of a scan read 5-10 % slow (profiles/r03_placement/README.md).  Load it first.
         float unused = 0.f;
         const double step_s = 1.1e-11 * (double)L.Nx * L.Ny + 1e-5;    // roughly what a launch takes
         GPF_TRY(plan_trial(h, D, &unused, (int)std::min(200.0, std::max(8.0, 0.012 / step_s))));
     }
-    GPF_TRY(plan_placement(h, D, placement_note));
     float best = 0.f;
     int best_chunks = nchunks;
     bool best_nt = nt;
     std::string seen;
-    for (int c : {one_per_simd, all_resident}) {
-        if (env_chunks && std::atoi(env_chunks) > 0) c = std::atoi(env_chunks);
-        for (int pol = 0; pol < (nt_possible && !env_nt ? 2 : 1); ++pol) {
-            const bool cand_nt = env_nt ? nt : (pol == 1);
-            GPF_TRY(plan_apply(h, c, cand_nt));
-            float us = 0.f;
-            GPF_TRY(plan_trial(h, D, &us));
-            char buf[48];
-            std::snprintf(buf, sizeof buf, " %d/%s %.0f", h->nchunks2, cand_nt ? "nt" : "plain", us);
-            seen += buf;
-            if (best == 0.f || us < best) { best = us; best_chunks = c; best_nt = cand_nt; }
+    auto pick_plan = [&]() -> int {
+        best = 0.f;
+        seen.clear();
+        for (int c : {one_per_simd, all_resident}) {
+            if (env_chunks && std::atoi(env_chunks) > 0) c = std::atoi(env_chunks);
+            for (int pol = 0; pol < (nt_possible && !env_nt ? 2 : 1); ++pol) {
+                const bool cand_nt = env_nt ? nt : (pol == 1);
+                GPF_TRY(plan_apply(h, c, cand_nt));
+                float us = 0.f;
+                GPF_TRY(plan_trial(h, D, &us, 6, true));
+                char buf[48];
+                std::snprintf(buf, sizeof buf, " %d/%s %.0f", h->nchunks2, cand_nt ? "nt" : "plain", us);
+                seen += buf;
+                if (best == 0.f || us < best) { best = us; best_chunks = c; best_nt = cand_nt; }
+            }
+            if ((env_chunks && std::atoi(env_chunks) > 0) || one_per_simd == all_resident) break;
         }
-        if ((env_chunks && std::atoi(env_chunks) > 0) || one_per_simd == all_resident) break;
-    }
+        return plan_apply(h, best_chunks, best_nt);
+    };
+    // the plan on the memory the handle has, the memory under that plan (which pages are good depends on how many streams run),
+    // the plan once more on the memory kept
+    const bool verify = std::getenv("GPF_PLACEMENT_PRINT") && std::atoi(std::getenv("GPF_PLACEMENT_PRINT")) >= 2;
+    auto stamp = [&](const char* when) {
+        if (!verify) return;
+        int par = 0;
+        if (current_parity(h, &par) != GPF_OK) return;
+        std::fprintf(stderr, "[gpf] %-28s q[par] %p %016llx   master %p %016llx\n", when, (void*)h->q[par], field_checksum(h->stream, h->q[par], h->field_bytes),
+                     (void*)h->plan_master, h->plan_master ? field_checksum(h->stream, h->plan_master, h->field_bytes) : 0ull);
+    };
+    stamp("before the first plan");
+    GPF_TRY(pick_plan());
+    stamp("after the first plan");
+    const std::string first_seen = seen;
+    GPF_TRY(plan_placement(h, D, placement_note));
+    stamp("after the placement");
+    if (!placement_note.empty()) GPF_TRY(pick_plan());
+    stamp("after the second plan");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    field_free(h->plan_master);
+    h->plan_master = nullptr;
     GPF_TRY(plan_apply(h, best_chunks, best_nt));
-    std::snprintf(h->plan2_note, sizeof h->plan2_note, "%d chunks per strip, %s stores (timed, us:%s;%s)", h->nchunks2,
-                  h->nt_stores2 ? "non-temporal" : "plain", seen.c_str(), placement_note.c_str());
+    std::snprintf(h->plan2_note, sizeof h->plan2_note, "%d chunks per strip, %s stores (timed, us:%s;%s%s%s)", h->nchunks2,
+                  h->nt_stores2 ? "non-temporal" : "plain", seen.c_str(), placement_note.c_str(),
+                  placement_note.empty() ? "" : "; before the placement:", placement_note.empty() ? "" : first_seen.c_str());
     DBG("plan_step2: %s", h->plan2_note);
     h->plan2_valid = true;
     return GPF_OK;

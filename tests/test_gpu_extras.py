@@ -196,3 +196,44 @@ np.savez(sys.argv[1], **out)
         outs.append(np.load(tmp_path / f'{tag}.npz'))
     for k in outs[0].files:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_large_fields_come_back_whole_after_other_handles_are_destroyed(hiplib):
+    """Large fields are ranges of virtual addresses backed by shuffled 16-MiB pieces of device memory (csrc/api.hip: field_malloc),
+    and the placement search allocates and returns a dozen of them per handle.  Handles are created, stepped and destroyed in
+    turn: every one of a set of identical problems must produce the same bits -- a range returned with a live mapping inside
+    would hand the next field another field's pages -- and the device memory in use must return to where it started."""
+    import gc
+    import torch
+    from gapflow_amd import Problem
+    import reference_suite as rs
+    text = rs.JOURNAL_2D.format(dx='1.e-5', dy='1.e-5', n=2048)
+
+    def run(nsteps):
+        p = Problem.from_string(text)
+        p._pre_run()
+        p._advance(nsteps, honor_stop=False)
+        return p
+
+    first = run(6)
+    ref = first.q.copy()
+    assert np.isfinite(ref).all() and np.abs(ref[0] - 877.7007).max() > 0.0          # the field has moved
+    del first
+    gc.collect()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    keep = []
+    for k in range(4):
+        a, b = run(6), run(6)                   # two alive at once, their searches interleaved with each other's fields
+        np.testing.assert_array_equal(a.q, ref)
+        np.testing.assert_array_equal(b.q, ref)
+        keep.append(a if k % 2 == 0 else b)     # some survive the others' destruction ...
+        del a, b
+        gc.collect()
+    for p in keep:                              # ... and still hold and advance their own state
+        np.testing.assert_array_equal(p.q, ref)
+    del keep, p
+    gc.collect()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert abs(free1 - free0) < (64 << 20), f'device memory in use changed by {(free0 - free1) / 2**20:.0f} MiB'
