@@ -135,7 +135,7 @@ struct gpf_handle {
     Strip2Geom geom2[2];
     int nchunks2 = 0, nblocks2 = 0, npartials2_cap = 0, nblock_partials_cap = 0;
     bool plan2_valid = false;
-    bool nt_stores2 = false;                // k_step2 writes q with the non-temporal hint (plan_step2)
+    int nt_policy2 = 0;                     // k_step2's traffic with the non-temporal hint: 0 none, 1 the stores, 2 stores and loads (plan_step2)
     StepState* st_trial = nullptr;          // plan_step2's timing launches commit into this copy of the run state
     double* plan_master = nullptr;          // copy of the current state while plan_step2 runs its trials
     char plan2_note[400] = "";              // how the plan was arrived at (gpf_plan_note)
@@ -853,12 +853,12 @@ constexpr int K2_LONG_MARCH_ROWS = 100;    // rows per wave from which plan_step
 
 // One wave marches over one row chunk of one 126-column strip; the chunks are sized so that all waves are resident at
 // once (a single round, no tail) when the problem is big enough: two waves per SIMD, or one.
-static int plan_apply(gpf_handle* h, int nchunks, bool nt) {
+static int plan_apply(gpf_handle* h, int nchunks, int nt) {
     const Layout& L = h->L;
     const int nstrips = std::max(h->geom2[0].nstrips, h->geom2[1].nstrips);
     nchunks = std::max(1, std::min(nchunks, std::max(1, L.Nx / 4)));        // small grids: >= 4 rows per chunk
     h->nchunks2 = nchunks;
-    h->nt_stores2 = nt;
+    h->nt_policy2 = nt;
     const int nwaves = nstrips * nchunks;
     h->nblocks2 = (((nwaves + 3) / 4) + 7) / 8 * 8;
     if (nwaves > h->npartials2_cap) {
@@ -930,9 +930,10 @@ static int plan_trial(gpf_handle* h, int D, float* us, int reps = 6, bool both =
 // next one the other way round, so a pair's figure is the sum of both directions.  The best pair becomes the handle's memory, then
 // (kernels that read the gap planes) the best home among a few of the remaining buffers for those; the rest is freed.  With S spares:
 // S + 2 + 12 trials of 7 launches and S + 1 buffers of transient memory (whole triples, as first tried: S trials for 3 S buffers).
-// GPF_PLACEMENT_TRIES sets S (default 10; 0: keep what hipMalloc gave); GPF_PLACEMENT_PRINT=1 prints the figures.
+// GPF_PLACEMENT_TRIES sets S (default 24: on one box 10 / 30 / 60 spares ended at 155.1, 152.6 / 151.1, 151.4 / 150.9 us per step in
+// separate processes; 0: keep the handle's own buffers); GPF_PLACEMENT_PRINT=1 prints the figures.
 static int plan_placement(gpf_handle* h, int D, std::string& note) {
-    int spares = 10;
+    int spares = 24;
     if (const char* s = std::getenv("GPF_PLACEMENT_TRIES")) spares = std::atoi(s);
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -1036,6 +1037,7 @@ static int plan_placement(gpf_handle* h, int D, std::string& note) {
 // stores, 4 % with two waves and plain ones; round 2's runs on other boxes favoured one wave per SIMD for both), so grids of a
 // million cells and more TIME the candidates once, on their own data (plan_trial: ~8 ms per handle), and keep the fastest.
 // Smaller grids and GPF_PLAN_TUNE=0 take the rule of thumb; GPF_CHUNKS / GPF_NT_STORES pin a choice (A/B runs).
+static const char* const NT_NAME[3] = {"plain loads and stores", "non-temporal stores", "non-temporal loads and stores"};
 static int plan_step2(gpf_handle* h, int D) {
     if (h->plan2_valid) return GPF_OK;
     const Layout& L = h->L;
@@ -1052,21 +1054,21 @@ static int plan_step2(gpf_handle* h, int D) {
     const double streamed = (double)L.plane * 8.0 * (6 + (topo_mode_of(h) == 0 ? 3 : 0) + (h->Ls ? 1 : 0));
     const bool nt_possible = streamed > 192.0 * 1024 * 1024;
     const char* env_chunks = std::getenv("GPF_CHUNKS");
-    const char* env_nt = std::getenv("GPF_NT_STORES");
+    const char* env_nt = std::getenv("GPF_NT") ? std::getenv("GPF_NT") : std::getenv("GPF_NT_STORES");      // 0, 1 (stores), 2 (stores and loads)
     const char* env_tune = std::getenv("GPF_PLAN_TUNE");
     // rule of thumb: one wave per SIMD for long marches (>= 100 rows per wave), non-temporal stores where they can pay
     int nchunks = all_resident;
     if (one_per_simd >= 1 && L.Nx / one_per_simd >= K2_LONG_MARCH_ROWS) nchunks = one_per_simd;
-    bool nt = nt_possible;
+    int nt = nt_possible ? 2 : 0;
     if (env_chunks && std::atoi(env_chunks) > 0) nchunks = std::atoi(env_chunks);
-    if (env_nt) nt = std::atoi(env_nt) != 0;
+    if (env_nt) nt = std::max(0, std::min(2, std::atoi(env_nt)));
     // (a slab tunes like any other handle: the trial launches commit into the scratch state and send nothing)
     const bool tune = !(env_tune && std::atoi(env_tune) == 0) && !h->split_edges && h->pre_run_done && (long long)L.Nx * L.Ny >= (1ll << 20) &&
                       one_per_simd >= 1 && L.Nx / one_per_simd >= 16 && !(env_chunks && env_nt);
     if (!tune) {
         GPF_TRY(plan_apply(h, nchunks, nt));
-        std::snprintf(h->plan2_note, sizeof h->plan2_note, "%d chunks per strip, %s stores (rule of thumb%s)", h->nchunks2,
-                      h->nt_stores2 ? "non-temporal" : "plain", (env_chunks || env_nt) ? ", pinned by the environment" : "");
+        std::snprintf(h->plan2_note, sizeof h->plan2_note, "%d chunks per strip, %s (rule of thumb%s)", h->nchunks2,
+                      NT_NAME[h->nt_policy2], (env_chunks || env_nt) ? ", pinned by the environment" : "");
         h->plan2_valid = true;
         return GPF_OK;
     }
@@ -1087,20 +1089,20 @@ static int plan_step2(gpf_handle* h, int D) {
     }
     float best = 0.f;
     int best_chunks = nchunks;
-    bool best_nt = nt;
+    int best_nt = nt;
     std::string seen;
     auto pick_plan = [&]() -> int {
         best = 0.f;
         seen.clear();
         for (int c : {one_per_simd, all_resident}) {
             if (env_chunks && std::atoi(env_chunks) > 0) c = std::atoi(env_chunks);
-            for (int pol = 0; pol < (nt_possible && !env_nt ? 2 : 1); ++pol) {
-                const bool cand_nt = env_nt ? nt : (pol == 1);
+            for (int pol = 0; pol < (nt_possible && !env_nt ? 3 : 1); ++pol) {
+                const int cand_nt = env_nt ? nt : pol;
                 GPF_TRY(plan_apply(h, c, cand_nt));
                 float us = 0.f;
                 GPF_TRY(plan_trial(h, D, &us, 6, true));
                 char buf[48];
-                std::snprintf(buf, sizeof buf, " %d/%s %.0f", h->nchunks2, cand_nt ? "nt" : "plain", us);
+                std::snprintf(buf, sizeof buf, " %d/%s %.0f", h->nchunks2, cand_nt == 2 ? "nt" : cand_nt == 1 ? "nts" : "plain", us);
                 seen += buf;
                 if (best == 0.f || us < best) { best = us; best_chunks = c; best_nt = cand_nt; }
             }
@@ -1130,8 +1132,8 @@ static int plan_step2(gpf_handle* h, int D) {
     field_free(h->plan_master);
     h->plan_master = nullptr;
     GPF_TRY(plan_apply(h, best_chunks, best_nt));
-    std::snprintf(h->plan2_note, sizeof h->plan2_note, "%d chunks per strip, %s stores (timed, us:%s;%s%s%s)", h->nchunks2,
-                  h->nt_stores2 ? "non-temporal" : "plain", seen.c_str(), placement_note.c_str(),
+    std::snprintf(h->plan2_note, sizeof h->plan2_note, "%d chunks per strip, %s (timed, us:%s;%s%s%s)", h->nchunks2,
+                  NT_NAME[h->nt_policy2], seen.c_str(), placement_note.c_str(),
                   placement_note.empty() ? "" : "; before the placement:", placement_note.empty() ? "" : first_seen.c_str());
     DBG("plan_step2: %s", h->plan2_note);
     h->plan2_valid = true;
@@ -1176,7 +1178,7 @@ static void fill_step2_args(gpf_handle* h, Step2Args& a2, int D, int honor_stop,
     a2.g1x = h->g1; a2.g1y = h->g1 + 3 * L.pitch;
     a2.st = h->st; a2.partials = h->partials; a2.block_partials = h->block_partials; a2.arrive = h->arrive;
     a2.log = h->log; a2.log_base = log_base; a2.log_cap = h->log_cap;
-    a2.L = L; a2.E = h->E; a2.G = G2; a2.nchunks = h->nchunks2; a2.fused = (fused ? 1 : 0) | (h->nt_stores2 ? 2 : 0); a2.honor_stop = honor_stop;
+    a2.L = L; a2.E = h->E; a2.G = G2; a2.nchunks = h->nchunks2; a2.fused = (fused ? 1 : 0) | (h->nt_policy2 >= 1 ? 2 : 0) | (h->nt_policy2 >= 2 ? 4 : 0); a2.honor_stop = honor_stop;
     const bool slab = slab_out != nullptr;
     for (int e = 0; e < 2; ++e) a2.seam[e] = (h->E.halo[e] == 2 && h->has_seam[e]) ? h->seam + (size_t)e * 8 * L.pitch : nullptr;
     a2.out = slab_out; a2.msg = (slab && !p2p) ? h->halo : nullptr; a2.p2p = p2p_args(h, p2p);

@@ -89,7 +89,7 @@ struct Step2Args {
     LogEntry* log; long long log_base, log_cap;
     Layout L; Edges E; Strip2Geom G;
     int nchunks;
-    int fused;                              // bit 0: edge work inside this kernel; bit 1: non-temporal stores (plan_step2)
+    int fused;                              // bit 0: edge work inside this kernel; bit 1: non-temporal stores, bit 2: non-temporal loads (plan_step2)
     int honor_stop;
 };
 
@@ -204,7 +204,9 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
     const Layout L = a.L;
     const Strip2Geom G = a.G;
     const bool fused = (a.fused & 1) != 0;
-    const bool nt_stores = (a.fused & 2) != 0;      // (rides in the same word: the march has no scalar register to spare)
+    // the cache policy rides in the same word and is tested bit by bit where it is used: the march has no scalar register to spare
+    // (one more live value tips some instantiations into a dead 16-byte spill slot, and a launch with a private segment costs ~4 us)
+    const int policy = __builtin_amdgcn_readfirstlane(a.fused);
 
     // ---- columns of this lane ----
     const bool y_periodic = a.E.rule[2][0] == BC_P;
@@ -290,19 +292,57 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
         const int ix = D > 0 ? min(n, n_last + 1) : L.Nx + 1 - min(n, n_last + 1);
         const long long rb = (long long)ix * L.pitch;       // wave-uniform
         const long long p1 = dummy ? 0 : L.plane, p2 = dummy ? 0 : 2 * L.plane;
-        asm_load16(r.q[0], lane_q + rb); asm_load16(r.q[1], lane_q + p1 + rb); asm_load16(r.q[2], lane_q + p2 + rb);
-        if (TOPO == 0) {
+        // ONE asm statement requests the whole row, with or without the non-temporal hint (plan_step2 decides per handle: the hint
+        // is worth 2-3 % where a step streams through HBM): the choice is a scalar branch inside the statement -- an if / else
+        // around two sets of loads would make hipcc join their destinations with copies of registers whose loads are in flight.
+        // "=&v": a destination must not share registers with the address of a later load of the same statement.
+        const double* const a0 = lane_q + rb; const double* const a1 = lane_q + p1 + rb; const double* const a2 = lane_q + p2 + rb;
+#define GPF_LD(d, a) "global_load_dwordx4 %" #d ", %" #a ", off\n\t"
+#define GPF_LDNT(d, a) "global_load_dwordx4 %" #d ", %" #a ", off nt\n\t"
+#define GPF_ROW_HEAD "s_cmp_lg_u32 %[nt], 0\n\ts_cbranch_scc1 .Lgpf_ldnt_%=\n\t"
+#define GPF_ROW_MID "s_branch .Lgpf_lddone_%=\n.Lgpf_ldnt_%=:\n\t"
+#define GPF_ROW_TAIL "\n.Lgpf_lddone_%=:"
+        if constexpr (TOPO == 0 && HAS_LS) {
             const double* t0 = dummy ? lane_q : lane_t;
-            asm_load16(r.t[0], t0 + rb); asm_load16(r.t[1], t0 + p1 + rb); asm_load16(r.t[2], t0 + p2 + rb);
-        } else if (TOPO == 1 || TOPO == 3) {
+            const double* const a3 = t0 + rb; const double* const a4 = t0 + p1 + rb; const double* const a5 = t0 + p2 + rb;
+            const double* const a6 = (dummy ? lane_q : lane_ls) + rb;
+            asm volatile(GPF_ROW_HEAD GPF_LD(0, 7) GPF_LD(1, 8) GPF_LD(2, 9) GPF_LD(3, 10) GPF_LD(4, 11) GPF_LD(5, 12) GPF_LD(6, 13) GPF_ROW_MID
+                         GPF_LDNT(0, 7) GPF_LDNT(1, 8) GPF_LDNT(2, 9) GPF_LDNT(3, 10) GPF_LDNT(4, 11) GPF_LDNT(5, 12) GPF_LDNT(6, 13) GPF_ROW_TAIL
+                         : "=&v"(r.q[0]), "=&v"(r.q[1]), "=&v"(r.q[2]), "=&v"(r.t[0]), "=&v"(r.t[1]), "=&v"(r.t[2]), "=&v"(r.ls[0])
+                         : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), [nt] "s"(policy & 4) : "memory", "scc");
+        } else if constexpr (TOPO == 0) {
+            const double* t0 = dummy ? lane_q : lane_t;
+            const double* const a3 = t0 + rb; const double* const a4 = t0 + p1 + rb; const double* const a5 = t0 + p2 + rb;
+            asm volatile(GPF_ROW_HEAD GPF_LD(0, 6) GPF_LD(1, 7) GPF_LD(2, 8) GPF_LD(3, 9) GPF_LD(4, 10) GPF_LD(5, 11) GPF_ROW_MID
+                         GPF_LDNT(0, 6) GPF_LDNT(1, 7) GPF_LDNT(2, 8) GPF_LDNT(3, 9) GPF_LDNT(4, 10) GPF_LDNT(5, 11) GPF_ROW_TAIL
+                         : "=&v"(r.q[0]), "=&v"(r.q[1]), "=&v"(r.q[2]), "=&v"(r.t[0]), "=&v"(r.t[1]), "=&v"(r.t[2])
+                         : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), [nt] "s"(policy & 4) : "memory", "scc");
+        } else if constexpr (HAS_LS) {
+            const double* const a3 = (dummy ? lane_q : lane_ls) + rb;
+            asm volatile(GPF_ROW_HEAD GPF_LD(0, 4) GPF_LD(1, 5) GPF_LD(2, 6) GPF_LD(3, 7) GPF_ROW_MID
+                         GPF_LDNT(0, 4) GPF_LDNT(1, 5) GPF_LDNT(2, 6) GPF_LDNT(3, 7) GPF_ROW_TAIL
+                         : "=&v"(r.q[0]), "=&v"(r.q[1]), "=&v"(r.q[2]), "=&v"(r.ls[0])
+                         : "v"(a0), "v"(a1), "v"(a2), "v"(a3), [nt] "s"(policy & 4) : "memory", "scc");
+        } else {
+            asm volatile(GPF_ROW_HEAD GPF_LD(0, 3) GPF_LD(1, 4) GPF_LD(2, 5) GPF_ROW_MID GPF_LDNT(0, 3) GPF_LDNT(1, 4) GPF_LDNT(2, 5) GPF_ROW_TAIL
+                         : "=&v"(r.q[0]), "=&v"(r.q[1]), "=&v"(r.q[2])
+                         : "v"(a0), "v"(a1), "v"(a2), [nt] "s"(policy & 4) : "memory", "scc");
+        }
+#undef GPF_LD
+#undef GPF_LDNT
+#undef GPF_ROW_HEAD
+#undef GPF_ROW_MID
+#undef GPF_ROW_TAIL
+        if (TOPO == 1 || TOPO == 3) {
             r.th = uniform_load(a.topo_line + ix); r.thx = uniform_load(a.topo_line + (L.Nx + 2) + ix);
             r.thy = TOPO == 1 ? uniform_load(a.topo_line + 2 * (L.Nx + 2) + ix) : 0.0;
         }
-        if (HAS_LS) asm_load16(r.ls[0], (dummy ? lane_q : lane_ls) + rb);
     };
     // wait until row r has landed: exactly AHEAD row requests (NL loads each) have been issued after it
     constexpr bool HEAVY = Step2Weight<EOS, HAS_LS, PIEZO>::heavy;
-    constexpr int AHEAD_ROWS = PIEZO ? 1 : ((TOPO == 1 || TOPO == 3) ? (HEAVY ? 2 : GPF_K2_AHEAD_LINE) : GPF_K2_AHEAD);
+    // (TOPO 1 -- a row profile with all three of h, hx, hy, reached only through GPF_TOPO_GENERIC -- keeps six scalar registers per
+    // row buffer: with five buffers hipcc runs out of them)
+    constexpr int AHEAD_ROWS = PIEZO ? 1 : (TOPO == 3 ? (HEAVY ? 2 : GPF_K2_AHEAD_LINE) : GPF_K2_AHEAD);
     // The stores of the rows finished in between are vector-memory operations too and sit in the same counter, in issue order:
     // once the march is AHEAD rows past its first output row, every loop body since row r's request has issued three of them
     // (a wave with at least one output lane takes at least one of the three store branches below), so the exact number of younger
@@ -548,7 +588,7 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
                     // given `if (nt) __builtin_nontemporal_store(v, p); else *p = v;` hipcc sinks the two stores into one and
                     // drops the hint -- the library of the first half of round 3 held no `nt` store at all (llvm-objdump).
                     // s_nop: a store of more than 8 bytes must not be followed at once by a write of its data registers.
-                    if (nt_stores) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" :: "v"(p), "v"(v) : "memory");
+                    if (policy & 2) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" :: "v"(p), "v"(v) : "memory");
                     else *p = v;
 #else
                     *p = v;
