@@ -930,30 +930,21 @@ static int plan_trial(gpf_handle* h, int D, float* us, int reps = 6, bool both =
 // next one the other way round, so a pair's figure is the sum of both directions.  The best pair becomes the handle's memory, then
 // (kernels that read the gap planes) the best home among a few of the remaining buffers for those; the rest is freed.  With S spares:
 // S + 2 + 12 trials of 7 launches and S + 1 buffers of transient memory (whole triples, as first tried: S trials for 3 S buffers).
-// GPF_PLACEMENT_TRIES sets S (default 24: on one box 10 / 30 / 60 spares ended at 155.1, 152.6 / 151.1, 151.4 / 150.9 us per step in
-// separate processes; 0: keep the handle's own buffers); GPF_PLACEMENT_PRINT=1 prints the figures.
+// GPF_PLACEMENT_TRIES sets S (default: 24, and twelve more for as long as the last twelve still paid, up to 60 -- on one box 10 / 30 / 60
+// spares ended at 155.1, 152.6 / 151.1, 151.4 / 150.9 us per step in separate processes; 0: keep the handle's own buffers);
+// GPF_PLACEMENT_PRINT=1 prints the figures.
 static int plan_placement(gpf_handle* h, int D, std::string& note) {
-    int spares = 24;
-    if (const char* s = std::getenv("GPF_PLACEMENT_TRIES")) spares = std::atoi(s);
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    while (spares > 0 && (size_t)spares * h->field_bytes + (2ull << 30) > free_b) --spares;
-    if (spares <= 0 || !h->plan_master) return GPF_OK;
+    const char* env_tries = std::getenv("GPF_PLACEMENT_TRIES");
+    const int fixed = env_tries ? std::atoi(env_tries) : -1;            // -1: two batches of 12, then on while a batch still pays
+    if (fixed == 0 || !h->plan_master) return GPF_OK;
     const bool print = std::getenv("GPF_PLACEMENT_PRINT") && std::atoi(std::getenv("GPF_PLACEMENT_PRINT")) != 0;
     int par = 0;
     GPF_TRY(current_parity(h, &par));
     const bool planes = topo_mode_of(h) == 0;               // the kernel reads h->topo (otherwise the gap travels as a line)
     double* const master = h->plan_master;                  // the current state, never a candidate
     std::vector<double*> pool = {h->q[par], h->q[par ^ 1]};
-    for (int k = 0; k < spares; ++k) {
-        double* b = nullptr;
-        if (field_malloc((void**)&b, h->field_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-        GPF_TRY(field_zero(h->stream, b, h->field_bytes));
-        pool.push_back(b);
-    }
-    const int n = (int)pool.size();
-    std::vector<char> holds_state(n, 0);
-    holds_state[0] = 1;
+    std::vector<char> holds_state = {1, 0};
+    std::vector<float> w = {0.f, 0.f};
     // read pool[i], write pool[j]; `both`: and the other way round in every other launch (plan_trial restores the state in pool[i])
     auto trial = [&](int i, int j, float* us, bool both) -> int {
         if (!holds_state[i]) {
@@ -965,9 +956,35 @@ static int plan_placement(gpf_handle* h, int D, std::string& note) {
         return plan_trial(h, D, us, 6, both);
     };
     // phase 1: every buffer as the one WRITTEN (the state read from the handle's own buffer; that one is written reading its twin) --
-    // most of what distinguishes the buffers shows there (profiles/r03_placement/pair_matrices.txt)
-    std::vector<float> w(n, 0.f);
-    for (int k = 1; k < n; ++k) GPF_TRY(trial(0, k, &w[k], false));
+    // most of what distinguishes the buffers shows there (profiles/r03_placement/pair_matrices.txt).  The spares come in batches of
+    // twelve, all held to the end (freed memory comes straight back): two batches, then another one for as long as the last one
+    // lowered the best figure by more than 1 % (at most five; GPF_PLACEMENT_TRIES=n: n spares, no more, no less).
+    float best_w = 0.f;
+    for (int round = 0; round < (fixed > 0 ? 1 : 5); ++round) {
+        int want = fixed > 0 ? fixed : 12;
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        while (want > 0 && (size_t)want * h->field_bytes + (2ull << 30) > free_b) --want;
+        const size_t first = pool.size();
+        for (int k = 0; k < want; ++k) {
+            double* b = nullptr;
+            if (field_malloc((void**)&b, h->field_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+            GPF_TRY(field_zero(h->stream, b, h->field_bytes));
+            pool.push_back(b); holds_state.push_back(0); w.push_back(0.f);
+        }
+        if (pool.size() == first) break;
+        float batch_best = 0.f;
+        for (size_t k = first; k < pool.size(); ++k) {
+            GPF_TRY(trial(0, (int)k, &w[k], false));
+            if (batch_best == 0.f || w[k] < batch_best) batch_best = w[k];
+        }
+        const bool paid = best_w == 0.f || batch_best < 0.99f * best_w;
+        if (best_w == 0.f || batch_best < best_w) best_w = batch_best;
+        if (round >= 1 && !paid) break;
+    }
+    const int n = (int)pool.size();
+    if (n == 2) return GPF_OK;
+    GPF_TRY(trial(0, 1, &w[1], false));                     // the handle's own two: each written reading the other
     GPF_TRY(trial(1, 0, &w[0], false));
     std::vector<int> order(n);
     for (int k = 0; k < n; ++k) order[k] = k;
