@@ -450,14 +450,31 @@ GPF_HD GapCoef gap_coefficients(double h, double hx, double hy) {
     return g;
 }
 
+// p(rho) and 1/rho together.  Dowson-Higginson divides by (C2 - rho_c/rho0), the velocities by rho: ONE reciprocal of the product
+// serves both (a reciprocal with its two Newton steps costs as much as eight multiplications on the fp64 pipe, and the two
+// divisions were a quarter of a closure's arithmetic); the other laws keep their own forms.
+template <int EOS>
+GPF_HD double pressure_and_inverse_density(double rho, const Phys& P, double& inv_rho) {
+    if (EOS == EOS_DH) {
+        const double r = fmin(rho, P.e[4]);             // as eos_pressure<EOS_DH>
+        const double s = r * P.e[5];
+        const double t = P.e[3] - s;
+        const double inv = rcp(rho * t);
+        inv_rho = inv * t;
+        return P.e[1] + (P.e[2] * (s - 1.0)) * (inv * rho);
+    }
+    inv_rho = rcp(rho);
+    return eos_pressure<EOS>(rho, P);
+}
+
 template <int EOS>
 GPF_HD void cell_closure_ls0(double rho, double jx, double jy, const GapCoef& g, const Phys& P, CellFlux& o) {
 #ifdef GPF_STUB_CLOSURE     // diagnostic build: memory-access pattern of the step without its arithmetic
     o.p = rho; o.fx1 = rho + g.ih; o.fx2 = jx + g.a; o.fy2 = jy + g.b; o.s0 = g.ih; o.s1 = g.a; o.s2 = g.b;
     return;
 #endif
-    const double p = eos_pressure<EOS>(rho, P);
-    const double ir = rcp(rho);
+    double ir;
+    const double p = pressure_and_inverse_density<EOS>(rho, P, ir);
     const double mx = jx * ir, my = jy * ir;
     const double ax = g.a * mx, by = g.b * my;
     const double txx = fma(P.v1, ax, P.v2 * by);
@@ -510,8 +527,8 @@ GPF_HD void cell_closure_xonly(double rho, double jx, double jy, const RowCoef& 
     o.p = rho; o.fx1 = rho + r.A; o.fx2 = jx + r.C; o.fy2 = jy + r.B; o.s0 = r.S0; o.s1 = r.S1a; o.s2 = r.S2a;
     return;
 #endif
-    const double p = eos_pressure<EOS>(rho, P);
-    const double ir = rcp(rho);
+    double ir;
+    const double p = pressure_and_inverse_density<EOS>(rho, P, ir);
     const double mx = jx * ir, my = jy * ir;
     o.p = p;
     o.fx1 = fma(r.A, mx, p);
