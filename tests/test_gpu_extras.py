@@ -237,3 +237,30 @@ def test_large_fields_come_back_whole_after_other_handles_are_destroyed(hiplib):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert abs(free1 - free0) < (64 << 20), f'device memory in use changed by {(free0 - free1) / 2**20:.0f} MiB'
+
+
+def test_tuner_and_scattered_fields_change_no_bit_of_the_result(hiplib, monkeypatch):
+    """What a large handle decides by measurement before its first step -- waves per SIMD, cache hints on loads and stores, which
+    buffers its state lives in, and whether those buffers are scattered over shuffled pieces of device memory -- must not show in
+    the fields: the same problem with the tuner off and plain hipMalloc gives the same bits (the kinetic energy is summed in
+    another order: last bits only)."""
+    from gapflow_amd import Problem
+    import reference_suite as rs
+    text = rs.JOURNAL_2D.format(dx='1.e-5', dy='1.e-5', n=1536).replace('V: 0.', 'V: 0.03')
+
+    def run():
+        p = Problem.from_string(text)
+        p._pre_run()
+        p._advance(7, honor_stop=False)
+        return p.q.copy(), p.dt, p.kinetic_energy, p._lib.gpf_plan_note(p._h).decode()
+
+    q_tuned, dt_tuned, e_tuned, note = run()
+    assert 'timed' in note and 'placement' in note, note
+    monkeypatch.setenv('GPF_PLAN_TUNE', '0')
+    monkeypatch.setenv('GPF_SCATTER_MB', '0')
+    q_plain, dt_plain, e_plain, note_plain = run()
+    assert 'rule of thumb' in note_plain, note_plain
+    np.testing.assert_array_equal(q_tuned, q_plain)
+    assert dt_tuned == dt_plain
+    np.testing.assert_allclose(e_tuned, e_plain, rtol=1e-13)
+    print(f'\n[tuner] {note[:120]} ... | fields bitwise the untuned run\'s, Ekin rel. difference {abs(e_tuned - e_plain) / e_plain:.1e}')
