@@ -43,71 +43,122 @@ struct GpFieldArgs {
     double* blockmax;               // per-block max of d mean/d x_0 (WITH_GRAD) or nullptr
 };
 
-// 2^(j/64), j = 0..63, correctly rounded: the exponential below is exp(x) = 2^m 2^(j/64) exp(f) with |f| <= ln2 / 128, a
-// degree-5 polynomial.  Kernels copy the table into LDS once (gp_exp_table_to_lds) and index it per lane.
-__device__ __constant__ double gp_exp2_tab[64] = {
-    1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284,
-    1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199,
-    1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418,
-    1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812,
-    1.189207115002721, 1.202156731452703, 1.215247359980469, 1.22848053610687,
-    1.241857812073484, 1.255380757024691, 1.2690509571917332, 1.2828700160787783,
-    1.2968395546510096, 1.3109612115247644, 1.3252366431597413, 1.339667524053303,
-    1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112,
-    1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647,
-    1.4768261459394993, 1.4929077282912648, 1.5091644275934228, 1.5255981507445384,
-    1.5422108254079407, 1.559004400237837, 1.5759808451078865, 1.593142151342267,
-    1.6104903319492543, 1.6280274218573478, 1.645755478153965, 1.6636765803267364,
-    1.681792830507429, 1.7001063537185235, 1.718619298122478, 1.7373338352737062,
-    1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989,
-    1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656,
-    1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.978456026387951};
+// 2^(j/256), j = 0..255, correctly rounded: the exponential below is exp(x) = 2^m 2^(j/256) exp(f) with |f| <= ln2 / 512, a
+// degree-4 polynomial (f^5 / 120 < 4e-17).  Kernels copy the table into LDS once (gp_exp_table_to_lds) and index it per lane.
+constexpr int GP_EXP_N = 256;
+__device__ __constant__ double gp_exp2_tab[GP_EXP_N] = {
+    1.0, 1.0027112750502025, 1.0054299011128027, 1.0081558981184175,
+    1.0108892860517005, 1.0136300849514894, 1.016378314910953, 1.019133996077738,
+    1.0218971486541166, 1.0246677928971357, 1.0274459491187637, 1.030231637686041,
+    1.0330248790212284, 1.0358256936019572, 1.0386341019613787, 1.041450124688316,
+    1.0442737824274138, 1.0471050958792898, 1.0499440858006872, 1.0527907730046264,
+    1.0556451783605572, 1.0585073227945128, 1.061377227289262, 1.0642549128844645,
+    1.0671404006768237, 1.0700337118202419, 1.0729348675259756, 1.075843889062791,
+    1.0787607977571199, 1.0816856149932152, 1.0846183622133092, 1.0875590609177697,
+    1.0905077326652577, 1.0934643990728858, 1.0964290818163769, 1.099401802630222,
+    1.102382583307841, 1.1053714457017412, 1.1083684117236787, 1.1113735033448175,
+    1.1143867425958924, 1.1174081515673693, 1.1204377524096067, 1.12347556733302,
+    1.1265216186082418, 1.129575928566288, 1.1326385195987192, 1.1357094141578055,
+    1.1387886347566916, 1.1418762039695616, 1.1449721444318042, 1.148076478840179,
+    1.1511892299529827, 1.154310420590216, 1.1574400736337511, 1.1605782120274988,
+    1.1637248587775775, 1.1668800369524817, 1.1700437696832502, 1.1732160801636373,
+    1.1763969916502812, 1.1795865274628758, 1.182784710984341, 1.1859915656609938,
+    1.189207115002721, 1.1924313825831512, 1.1956643920398273, 1.1989061670743806,
+    1.202156731452703, 1.2054161090051239, 1.2086843236265816, 1.2119613992768012,
+    1.215247359980469, 1.2185422298274085, 1.2218460329727576, 1.2251587936371455,
+    1.22848053610687, 1.2318112847340759, 1.2351510639369334, 1.2384998981998165,
+    1.241857812073484, 1.245224830175258, 1.2486009771892048, 1.2519862778663162,
+    1.255380757024691, 1.2587844395497165, 1.2621973503942507, 1.2656195145788063,
+    1.2690509571917332, 1.2724917033894028, 1.275941778396392, 1.2794012075056693,
+    1.2828700160787783, 1.2863482295460256, 1.2898358734066657, 1.2933329732290895,
+    1.2968395546510096, 1.3003556433796506, 1.3038812651919358, 1.3074164459346773,
+    1.3109612115247644, 1.3145155879493546, 1.318079601266064, 1.3216532776031575,
+    1.3252366431597413, 1.3288297242059544, 1.3324325470831615, 1.3360451382041458,
+    1.339667524053303, 1.3432997311868353, 1.3469417862329458, 1.3505937158920345,
+    1.3542555469368927, 1.3579273062129011, 1.3616090206382248, 1.365300717204012,
+    1.3690024229745905, 1.3727141650876684, 1.3764359707545302, 1.380167867260238,
+    1.383909881963832, 1.387662042298529, 1.3914243757719262, 1.3951969099662003,
+    1.3989796725383112, 1.4027726912202048, 1.4065759938190154, 1.4103896082172707,
+    1.4142135623730951, 1.4180478843204152, 1.4218926021691656, 1.4257477441054942,
+    1.42961333839197, 1.433489413367789, 1.4373759974489824, 1.4412731191286257,
+    1.4451808069770467, 1.449099089642035, 1.4530279958490526, 1.4569675544014438,
+    1.460917794180647, 1.4648787441464057, 1.4688504333369818, 1.4728328908693675,
+    1.4768261459394993, 1.4808302278224719, 1.4848451658727524, 1.488870989524397,
+    1.4929077282912648, 1.4969554117672355, 1.5010140696264256, 1.5050837316234065,
+    1.5091644275934228, 1.5132561874526098, 1.5173590411982147, 1.5214730189088146,
+    1.5255981507445384, 1.529734466947287, 1.533881997840956, 1.5380407738316568,
+    1.5422108254079407, 1.5463921831410214, 1.550584877685, 1.5547889397770887,
+    1.559004400237837, 1.5632312899713576, 1.567469639965553, 1.5717194812923414,
+    1.5759808451078865, 1.5802537626528246, 1.5845382652524937, 1.588834384317164,
+    1.593142151342267, 1.597461597908627, 1.6017927556826934, 1.606135656416771,
+    1.6104903319492543, 1.6148568142048607, 1.6192351351948637, 1.6236253270173289,
+    1.6280274218573478, 1.632441451987275, 1.6368674497669644, 1.6413054476440063,
+    1.645755478153965, 1.6502175739206177, 1.6546917676561943, 1.6591780921616162,
+    1.6636765803267364, 1.6681872651305825, 1.6727101796415966, 1.6772453570178785,
+    1.681792830507429, 1.6863526334483934, 1.6909247992693053, 1.6955093614893326,
+    1.7001063537185235, 1.7047158096580513, 1.709337763100463, 1.713972247929926,
+    1.718619298122478, 1.723278947746274, 1.7279512309618377, 1.732636182022311,
+    1.7373338352737062, 1.7420442251551564, 1.746767386199169, 1.7515033530318782,
+    1.7562521603732995, 1.761013843037584, 1.7657884359332727, 1.7705759740635547,
+    1.7753764925265212, 1.7801900265154245, 1.785016611318935, 1.789856282321401,
+    1.7947090750031072, 1.7995750249405351, 1.804454167806624, 1.809346539371032,
+    1.8142521755003989, 1.8191711121586085, 1.8241033854070534, 1.8290490314048973,
+    1.8340080864093424, 1.8389805867758937, 1.843966568958626, 1.8489660695104508,
+    1.8539791250833855, 1.8590057724288205, 1.864046048397789, 1.8690999899412386,
+    1.8741676341103, 1.8792490180565602, 1.8843441790323345, 1.8894531543909392,
+    1.8945759815869656, 1.8997126981765553, 1.9048633418176741, 1.9100279502703899,
+    1.9152065613971474, 1.9203992131630474, 1.925605943636125, 1.930826790987627,
+    1.9360617934922943, 1.9413109895286405, 1.9465744175792332, 1.9518521162309783,
+    1.9571441241754002, 1.9624504802089273, 1.9677712232331759, 1.9731063922552343,
+    1.978456026387951, 1.9838201648502194, 1.9891988469672663, 1.9945921121709402};
 
-// called by all threads of a block before the first matern_terms; `tab` is a __shared__ double[64]
+// called by all threads of a block before the first matern_terms; `tab` is a __shared__ double[GP_EXP_N]
 __device__ __forceinline__ void gp_exp_table_to_lds(double* tab) {
-    if (threadIdx.x < 64) tab[threadIdx.x] = gp_exp2_tab[threadIdx.x];
+    for (int i = threadIdx.x; i < GP_EXP_N; i += blockDim.x) tab[i] = gp_exp2_tab[i];
     __syncthreads();
 }
 
 // Matern-3/2 pieces for t = 3 r^2 >= 0:  s = sqrt(t),  e = exp(-s);  k = A (1 + s) e,  dk/ds ~ s e.
-// These kernels are bound by the fp64 units (on gfx950 only the double-precision operations cost four cycles per wave; moves,
-// integer operations and LDS reads ride along), so the NUMBER of fp64 operations of this function is their speed:
-//   * sqrt: v_rsq_f64 + one Halley step (5 operations) instead of the range-scaled library sqrt;
-//   * exp (argument <= 0): reduction by ln2/64 (round to nearest, hi/lo split), a 64-entry table of 2^(j/64) in LDS, a
-//     degree-5 polynomial and v_ldexp_f64 -- 12 operations instead of the 19 of a degree-13 polynomial after a reduction by ln 2
-//     (and far fewer than the library exp with its overflow / underflow selects).
-// Accurate to 1.5 ulp (exp) and 1.5 ulp (sqrt) on the range that matters; every kernel below (K, Ks, mean, variance, likelihood)
-// uses this one function, so K and Ks stay consistent.
+// These kernels are bound by the fp64 units (on gfx950 every vector operation costs four cycles per wave, the double-precision
+// ones included), so the NUMBER of operations of this function is their speed:
+//   * sqrt: v_rsq_f64 + one Halley step (5 operations) instead of the range-scaled library sqrt; callers start their sum of squares
+//     at 1e-300 instead of 0, which keeps t = 0 away from rsq at no cost (k = A exactly there);
+//   * exp (argument <= 0): reduction by ln2/256 with the rounding done by the adder (x c + 1.5 2^52: the integer sits in the low
+//     word of the sum, no rint and no conversion), a 256-entry table of 2^(j/256) in LDS, a degree-4 polynomial and v_ldexp_f64 --
+//     10 operations instead of the 12 of round 2's 64-entry / degree-5 form and the 19 of a degree-13 polynomial after a
+//     reduction by ln 2 (and far fewer than the library exp with its overflow / underflow selects).
+// Accurate to 1.5 ulp (exp) and 1.5 ulp (sqrt) on the range that matters (tools/matern_accuracy.hip); every kernel below (K, Ks,
+// mean, variance, likelihood) uses this one function, so K and Ks stay consistent.
 __device__ __forceinline__ void matern_terms(double t, double& s, double& e, const double* __restrict__ tab) {
-    const double tt = fmax(t, 1e-300);                      // t = 0 -> s = 1e-150, k = A exactly
-    const double y = __builtin_amdgcn_rsq(tt);              // ~24-bit seed
+    const double y = __builtin_amdgcn_rsq(t);               // ~24-bit seed (t >= 3e-300: the callers' sums start at 1e-300)
 #ifdef GPF_GP_GOLDSCHMIDT_SQRT  // (A/B: two Goldschmidt steps, 7 operations, 1.1 ulp)
-    double g = tt * y, h = 0.5 * y;
+    double g = t * y, h = 0.5 * y;
     double r = fma(-h, g, 0.5);
     g = fma(g, r, g); h = fma(h, r, h);
     r = fma(-h, g, 0.5);
     s = fma(g, r, g);
 #else
     // one Halley step: with c = t y^2 = 1 + O(2^-24), sqrt(t) = t y (15/8 - 5/4 c + 3/8 c^2) (1 + O(2^-72)): 5 operations, 1.5 ulp
-    const double g = tt * y, c = g * y;
+    const double g = t * y, c = g * y;
     double q = fma(0.375, c, -1.25);
     q = fma(q, c, 1.875);
     s = g * q;
 #endif
-    // exp(-800) = 0 in fp64 anyway; the clamp keeps the reduction exact (n < 2^21) and the integer conversion in range for the
-    // absurd distances a line-search probe of the training can produce (unclamped, t > 1e14 returned inf: tools/matern_accuracy.hip)
+    // exp(-800) = 0 in fp64 anyway; the clamp keeps the reduction exact (|n| < 2^19) and the integer in range for the absurd
+    // distances a line-search probe of the training can produce (unclamped, t > 1e14 returned inf: tools/matern_accuracy.hip)
     const double x = -fmin(s, 800.0);
-    const double n = __builtin_rint(x * 92.332482616893657);            // 64 / ln 2
-    double f = fma(n, -0.010830424693267560, x);            // ln2 / 64 = hi + lo; hi = (ln2 hi) / 64 keeps its 21 trailing zero bits
-    f = fma(n, -2.9815858269852933e-12, f);
-    double p = 8.3333333333333332e-03;                      // 1/5!
-    p = fma(p, f, 4.1666666666666664e-02);                  // 1/4!
+    const double magic = 6755399441055744.0;                // 1.5 * 2^52: x c + magic is rounded to an integer by the addition
+    const double nm = fma(x, 369.32993046757463, magic);    // 256 / ln 2
+    const double n = nm - magic;
+    double f = fma(n, -0.0027076061733168900, x);           // ln2 / 256 = hi + lo; hi = (ln2 hi) / 256 keeps its 21 trailing zero bits
+    f = fma(n, -7.4539645674632333e-13, f);
+    double p = 4.1666666666666664e-02;                      // 1/4!
     p = fma(p, f, 1.6666666666666666e-01);                  // 1/3!
     p = fma(p, f, 0.5);
     p = fma(p, f, 1.0);
     p = fma(p, f, 1.0);
-    const int ni = (int)n;
-    e = ldexp(tab[ni & 63] * p, ni >> 6);                   // arithmetic shift: floor(n / 64) for the negative n
+    const int ni = __double2loint(nm);                      // two's complement of n in the low word (|n| < 2^31)
+    e = ldexp(tab[ni & (GP_EXP_N - 1)] * p, ni >> 8);       // arithmetic shift: floor(n / 256) for the negative n
 }
 
 __device__ __forceinline__ double gp_feature(const GpFieldArgs& a, int f, long long o) {
@@ -118,11 +169,11 @@ __device__ __forceinline__ double gp_feature(const GpFieldArgs& a, int f, long l
 
 // K (column-major n x n) = k(Z, Z) + sigma^2 I, with Z already in kernel coordinates
 __global__ void k_gp_matrix(const double* Z, int n, int d, double amp, double sigma2, double* K) {
-    __shared__ double exptab[64];
+    __shared__ double exptab[GP_EXP_N];
     gp_exp_table_to_lds(exptab);
     const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
     if (i >= n) return;
-    double r2 = 0.0;
+    double r2 = 1e-300;      // (not 0: matern_terms takes rsq of 3 r2)
     for (int k = 0; k < d; ++k) {
         const double t = Z[i * d + k] - Z[j * d + k];
         r2 += t * t;
@@ -138,7 +189,7 @@ __global__ __launch_bounds__(256) void k_gp_mean(const GpModelDev g, const GpFie
     __shared__ double sZ[GP_CHUNK * D];
     __shared__ double sA[GP_CHUNK * M];
     __shared__ double sred[4];
-    __shared__ double exptab[64];
+    __shared__ double exptab[GP_EXP_N];
     gp_exp_table_to_lds(exptab);
     const long long w = a.L.Ny + 2, ncell = (long long)(a.L.Nx + 2) * w;
     const long long cell = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -160,7 +211,7 @@ __global__ __launch_bounds__(256) void k_gp_mean(const GpModelDev g, const GpFie
         for (int t = threadIdx.x; t < cnt * M; t += blockDim.x) sA[t] = g.alpha[(long long)(t / cnt) * g.n + base + (t % cnt)];
         __syncthreads();
         for (int i = 0; i < cnt; ++i) {
-            double r2 = 0.0, d0 = 0.0;
+            double r2 = 1e-300, d0 = 0.0;     // (not 0: matern_terms takes rsq of 3 r2)
             for (int k = 0; k < D; ++k) {
                 const double t = sZ[i * D + k] - z[k];
                 if (k == 0) d0 = t;
@@ -207,7 +258,7 @@ __global__ void k_gp_maxreduce(const double* in, int n, double scale, double* ou
 template <int D>
 __global__ __launch_bounds__(256) void k_gp_ks_tile(const GpModelDev g, const GpFieldArgs a, long long cell0, int ncols,
                                                     double* Ks) {
-    __shared__ double exptab[64];
+    __shared__ double exptab[GP_EXP_N];
     gp_exp_table_to_lds(exptab);
     const long long w = a.L.Ny + 2;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;      // training point
@@ -215,7 +266,7 @@ __global__ __launch_bounds__(256) void k_gp_ks_tile(const GpModelDev g, const Gp
     if (i >= g.n || j >= ncols) return;
     const long long cell = cell0 + j;
     const long long o = a.L.at((int)(cell / w), (int)(cell % w));
-    double r2 = 0.0;
+    double r2 = 1e-300;      // (not 0: matern_terms takes rsq of 3 r2)
     for (int k = 0; k < D; ++k) {
         const double t = g.Z[(long long)i * D + k] - gp_feature(a, g.dims[k], o) * g.fscale[k];
         r2 += t * t;
@@ -315,7 +366,7 @@ __global__ __launch_bounds__(64 * GPV_WAVES) void k_gp_var_fused(const GpModelDe
     __shared__ double Bs[4][GPV_KB * GPV_CELLS];        // two phases (double buffer) x two batches per phase
     auto bs_index = [](int kk, int cell) { return (((kk >> 2) * 4 + (cell >> 4)) * 4 + (kk & 3)) * 16 + (cell & 15); };
     __shared__ double part[GPV_WAVES][GPV_CELLS];
-    __shared__ double exptab[64];
+    __shared__ double exptab[GP_EXP_N];
     gp_exp_table_to_lds(exptab);
     const int n = g.n;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -346,7 +397,7 @@ __global__ __launch_bounds__(64 * GPV_WAVES) void k_gp_var_fused(const GpModelDe
         val = z[0] + k;
 #else
         if (k < n) {
-            double r2 = 0.0;
+            double r2 = 1e-300;      // (not 0: matern_terms takes rsq of 3 r2)
             for (int d = 0; d < D; ++d) {
                 const double t = g.Z[(long long)k * D + d] - z[d];
                 r2 += t * t;
@@ -457,13 +508,13 @@ template <int D>
 __global__ __launch_bounds__(256) void k_gp_nll_grad(const double* __restrict__ X, const double* __restrict__ alpha, const double* __restrict__ Kinv,
                                                      int n, int m, double amp, const double* __restrict__ inv_scale, double* __restrict__ partial) {
     __shared__ double red[4][1 + D];
-    __shared__ double exptab[64];
+    __shared__ double exptab[GP_EXP_N];
     gp_exp_table_to_lds(exptab);
     const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
     double acc[1 + D];
     for (int k = 0; k <= D; ++k) acc[k] = 0.0;
     if (i < n) {
-        double t[D], r2 = 0.0;
+        double t[D], r2 = 1e-300;       // (not 0: matern_terms takes rsq of 3 r2)
         for (int k = 0; k < D; ++k) {
             const double dz = (X[(long long)i * D + k] - X[(long long)j * D + k]) * inv_scale[k];
             t[k] = dz * dz;
@@ -493,11 +544,11 @@ __global__ __launch_bounds__(256) void k_gp_nll_grad(const double* __restrict__ 
 template <int D>
 __global__ void k_gp_nll_matrix(const double* __restrict__ X, int n, double amp, const double* __restrict__ inv_scale, double sigma2,
                                 double* __restrict__ K) {
-    __shared__ double exptab[64];
+    __shared__ double exptab[GP_EXP_N];
     gp_exp_table_to_lds(exptab);
     const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
     if (i >= n) return;
-    double r2 = 0.0;
+    double r2 = 1e-300;      // (not 0: matern_terms takes rsq of 3 r2)
     for (int k = 0; k < D; ++k) {
         const double dz = (X[(long long)i * D + k] - X[(long long)j * D + k]) * inv_scale[k];
         r2 += dz * dz;
