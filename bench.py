@@ -83,7 +83,8 @@ def measured_traffic(kind):
     pdir = os.path.join(ROOT, 'profiles')
     if N_GRID != 4096 or not os.path.isdir(pdir):
         return None, None
-    for d in sorted(os.listdir(pdir)):
+    # the newest set: highest round, and within a round the one named *_final (the others are earlier stages of that round)
+    for d in sorted(os.listdir(pdir), key=lambda d: (d[:3], 'final' in d, d)):
         f = os.path.join(pdir, d, f'traffic_{kind}.json')
         if os.path.exists(f):
             best = (json.load(open(f))['hbm_bytes_per_launch'], f'profiles/{d}/traffic_{kind}.json')
