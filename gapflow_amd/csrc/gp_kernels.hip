@@ -29,9 +29,9 @@ constexpr int GP_CHUNK = 512;        // training points staged in LDS per pass
 struct GpModelDev {
     int n, d, m;
     int dims[GP_MAX_D];             // feature index of each active dimension: 0..2 q, 3..5 topography, 6 extra
-    double fscale[GP_MAX_D];        // inv_scale / X_scale: raw feature -> kernel coordinate
+    double fscale[GP_MAX_D];        // sqrt3 inv_scale / X_scale: raw feature -> kernel coordinate
     double amp, yscale;
-    const double* Z;                // [n][d] training inputs in kernel coordinates (X_norm * inv_scale)
+    const double* Z;                // [n][d] training inputs in kernel coordinates (sqrt3 X_norm * inv_scale: |z - z'| IS sqrt3 r)
     const double* alpha;            // [m][n]
     const double* L;                // [n][n] column-major lower Cholesky factor
 };
@@ -46,6 +46,7 @@ struct GpFieldArgs {
 // 2^(j/256), j = 0..255, correctly rounded: the exponential below is exp(x) = 2^m 2^(j/256) exp(f) with |f| <= ln2 / 512, a
 // degree-4 polynomial (f^5 / 120 < 4e-17).  Kernels copy the table into LDS once (gp_exp_table_to_lds) and index it per lane.
 constexpr int GP_EXP_N = 256;
+constexpr double GP_SQRT3 = 1.7320508075688772;     // folded into the kernel coordinates (GpModelDev::Z, fscale) by the host
 __device__ __constant__ double gp_exp2_tab[GP_EXP_N] = {
     1.0, 1.0027112750502025, 1.0054299011128027, 1.0081558981184175,
     1.0108892860517005, 1.0136300849514894, 1.016378314910953, 1.019133996077738,
@@ -112,9 +113,13 @@ __device__ __constant__ double gp_exp2_tab[GP_EXP_N] = {
     1.9571441241754002, 1.9624504802089273, 1.9677712232331759, 1.9731063922552343,
     1.978456026387951, 1.9838201648502194, 1.9891988469672663, 1.9945921121709402};
 
-// called by all threads of a block before the first matern_terms; `tab` is a __shared__ double[GP_EXP_N]
+// called by all threads of a block before the first matern_terms; `tab` is a __shared__ double[GP_EXP_LDS].  The entry behind the
+// table holds 3/8, the one constant of the square root that the instruction encoding cannot carry: read from LDS once per kernel
+// it lives in a register, written as a literal it costs two moves per evaluation.
+constexpr int GP_EXP_LDS = GP_EXP_N + 1;
 __device__ __forceinline__ void gp_exp_table_to_lds(double* tab) {
     for (int i = threadIdx.x; i < GP_EXP_N; i += blockDim.x) tab[i] = gp_exp2_tab[i];
+    if (threadIdx.x == 0) tab[GP_EXP_N] = 0.375;
     __syncthreads();
 }
 
@@ -138,10 +143,12 @@ __device__ __forceinline__ void matern_terms(double t, double& s, double& e, con
     r = fma(-h, g, 0.5);
     s = fma(g, r, g);
 #else
-    // one Halley step: with c = t y^2 = 1 + O(2^-24), sqrt(t) = t y (15/8 - 5/4 c + 3/8 c^2) (1 + O(2^-72)): 5 operations, 1.5 ulp
-    const double g = t * y, c = g * y;
-    double q = fma(0.375, c, -1.25);
-    q = fma(q, c, 1.875);
+    // one Halley step around c = t y^2 = 1 + d, |d| < 1.1e-7: sqrt(t) = t y (1 - d/2 + 3/8 d^2) (1 + O(d^3)).  Written in d, with
+    // the constants the instruction encoding holds (-1, -1/2, 1) and 3/8 from a register (tab[GP_EXP_N]; 1/2 in its place costs
+    // 6 ulp: d^2 / 8 = 1.4e-15) -- the form 15/8 - 5/4 c + 3/8 c^2 spent two moves per evaluation on its constants.  5 operations.
+    const double g = t * y;
+    const double d = fma(g, y, -1.0);
+    const double q = fma(d, fma(d, tab[GP_EXP_N], -0.5), 1.0);
     s = g * q;
 #endif
     // exp(-800) = 0 in fp64 anyway; the clamp keeps the reduction exact (|n| < 2^19) and the integer in range for the absurd
@@ -167,29 +174,30 @@ __device__ __forceinline__ double gp_feature(const GpFieldArgs& a, int f, long l
     return a.Ls ? a.Ls[o] : 0.0;
 }
 
-// K (column-major n x n) = k(Z, Z) + sigma^2 I, with Z already in kernel coordinates
+// K (column-major n x n) = k(Z, Z) + sigma^2 I, with Z already in kernel coordinates (the factor sqrt3 of the Matern argument
+// folded into them: one multiplication less per evaluation in every kernel that works from them)
 __global__ void k_gp_matrix(const double* Z, int n, int d, double amp, double sigma2, double* K) {
-    __shared__ double exptab[GP_EXP_N];
+    __shared__ double exptab[GP_EXP_LDS];
     gp_exp_table_to_lds(exptab);
     const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
     if (i >= n) return;
-    double r2 = 1e-300;      // (not 0: matern_terms takes rsq of 3 r2)
+    double r2 = 1e-300;      // (not 0: matern_terms takes rsq of it)
     for (int k = 0; k < d; ++k) {
         const double t = Z[i * d + k] - Z[j * d + k];
         r2 += t * t;
     }
     double r, e;                                      // r = sqrt3 * |dz|
-    matern_terms(3.0 * r2, r, e, exptab);
+    matern_terms(r2, r, e, exptab);
     K[i + (long long)j * n] = amp * (1.0 + r) * e + (i == j ? sigma2 : 0.0);
 }
 
 // posterior mean (and optionally d mean/d x_0) at every cell of the grid incl. ghost cells
 template <int D, int M, bool WITH_GRAD>
-__global__ __launch_bounds__(256) void k_gp_mean(const GpModelDev g, const GpFieldArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_gp_mean(const GpModelDev g, const GpFieldArgs a) {
     __shared__ double sZ[GP_CHUNK * D];
     __shared__ double sA[GP_CHUNK * M];
     __shared__ double sred[4];
-    __shared__ double exptab[GP_EXP_N];
+    __shared__ double exptab[GP_EXP_LDS];
     gp_exp_table_to_lds(exptab);
     const long long w = a.L.Ny + 2, ncell = (long long)(a.L.Nx + 2) * w;
     const long long cell = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -210,15 +218,16 @@ __global__ __launch_bounds__(256) void k_gp_mean(const GpModelDev g, const GpFie
         for (int t = threadIdx.x; t < cnt * D; t += blockDim.x) sZ[t] = g.Z[(long long)base * D + t];
         for (int t = threadIdx.x; t < cnt * M; t += blockDim.x) sA[t] = g.alpha[(long long)(t / cnt) * g.n + base + (t % cnt)];
         __syncthreads();
+#pragma unroll 4
         for (int i = 0; i < cnt; ++i) {
-            double r2 = 1e-300, d0 = 0.0;     // (not 0: matern_terms takes rsq of 3 r2)
+            double r2 = 1e-300, d0 = 0.0;     // (not 0: matern_terms takes rsq of it)
             for (int k = 0; k < D; ++k) {
                 const double t = sZ[i * D + k] - z[k];
                 if (k == 0) d0 = t;
                 r2 += t * t;
             }
             double r, e;
-            matern_terms(3.0 * r2, r, e, exptab);
+            matern_terms(r2, r, e, exptab);
             const double kv = fma(r, e, e);
             for (int k = 0; k < M; ++k) acc[k] += sA[k * cnt + i] * kv;
             if (WITH_GRAD) gacc += sA[i] * d0 * e;
@@ -229,8 +238,9 @@ __global__ __launch_bounds__(256) void k_gp_mean(const GpModelDev g, const GpFie
         if (M > 1 && a.out1) a.out1[o] = g.amp * acc[M - 1] * g.yscale;
     }
     if (WITH_GRAD) {
-        // d mean/d x_0 in normalised units: 3 A s_0 sum_i alpha_i (z_i0 - z*_0) e_i ; s_0 = fscale * X_scale
-        double v = active ? 3.0 * g.amp * gacc : -__builtin_inf();
+        // d mean/d x_0 = 3 A s_0 sum_i alpha_i s_0 (x_i0 - x*_0) e_i = A (sqrt3 s_0) sum_i alpha_i (z_i0 - z*_0) e_i in the sqrt3-scaled
+        // coordinates; the host multiplies by fscale_0 = sqrt3 s_0 / X_scale_0
+        double v = active ? g.amp * gacc : -__builtin_inf();
         for (int s = 32; s >= 1; s >>= 1) v = nanmax(v, __shfl_down(v, s));
         if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = v;
         __syncthreads();
@@ -258,7 +268,7 @@ __global__ void k_gp_maxreduce(const double* in, int n, double scale, double* ou
 template <int D>
 __global__ __launch_bounds__(256) void k_gp_ks_tile(const GpModelDev g, const GpFieldArgs a, long long cell0, int ncols,
                                                     double* Ks) {
-    __shared__ double exptab[GP_EXP_N];
+    __shared__ double exptab[GP_EXP_LDS];
     gp_exp_table_to_lds(exptab);
     const long long w = a.L.Ny + 2;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;      // training point
@@ -266,13 +276,13 @@ __global__ __launch_bounds__(256) void k_gp_ks_tile(const GpModelDev g, const Gp
     if (i >= g.n || j >= ncols) return;
     const long long cell = cell0 + j;
     const long long o = a.L.at((int)(cell / w), (int)(cell % w));
-    double r2 = 1e-300;      // (not 0: matern_terms takes rsq of 3 r2)
+    double r2 = 1e-300;      // (not 0: matern_terms takes rsq of it)
     for (int k = 0; k < D; ++k) {
         const double t = g.Z[(long long)i * D + k] - gp_feature(a, g.dims[k], o) * g.fscale[k];
         r2 += t * t;
     }
     double r, e;
-    matern_terms(3.0 * r2, r, e, exptab);
+    matern_terms(r2, r, e, exptab);
     Ks[i + (long long)j * g.n] = g.amp * (1.0 + r) * e;
 }
 
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(64 * GPV_WAVES) void k_gp_var_fused(const GpModelDe
     __shared__ double Bs[4][GPV_KB * GPV_CELLS];        // two phases (double buffer) x two batches per phase
     auto bs_index = [](int kk, int cell) { return (((kk >> 2) * 4 + (cell >> 4)) * 4 + (kk & 3)) * 16 + (cell & 15); };
     __shared__ double part[GPV_WAVES][GPV_CELLS];
-    __shared__ double exptab[GP_EXP_N];
+    __shared__ double exptab[GP_EXP_LDS];
     gp_exp_table_to_lds(exptab);
     const int n = g.n;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -397,13 +407,13 @@ __global__ __launch_bounds__(64 * GPV_WAVES) void k_gp_var_fused(const GpModelDe
         val = z[0] + k;
 #else
         if (k < n) {
-            double r2 = 1e-300;      // (not 0: matern_terms takes rsq of 3 r2)
+            double r2 = 1e-300;      // (not 0: matern_terms takes rsq of it)
             for (int d = 0; d < D; ++d) {
                 const double t = g.Z[(long long)k * D + d] - z[d];
                 r2 += t * t;
             }
             double r, e;
-            matern_terms(3.0 * r2, r, e, exptab);
+            matern_terms(r2, r, e, exptab);
             val = g.amp * (1.0 + r) * e;
         }
 #endif
@@ -508,13 +518,13 @@ template <int D>
 __global__ __launch_bounds__(256) void k_gp_nll_grad(const double* __restrict__ X, const double* __restrict__ alpha, const double* __restrict__ Kinv,
                                                      int n, int m, double amp, const double* __restrict__ inv_scale, double* __restrict__ partial) {
     __shared__ double red[4][1 + D];
-    __shared__ double exptab[GP_EXP_N];
+    __shared__ double exptab[GP_EXP_LDS];
     gp_exp_table_to_lds(exptab);
     const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
     double acc[1 + D];
     for (int k = 0; k <= D; ++k) acc[k] = 0.0;
     if (i < n) {
-        double t[D], r2 = 1e-300;       // (not 0: matern_terms takes rsq of 3 r2)
+        double t[D], r2 = 1e-300;       // (not 0: matern_terms takes rsq of it)
         for (int k = 0; k < D; ++k) {
             const double dz = (X[(long long)i * D + k] - X[(long long)j * D + k]) * inv_scale[k];
             t[k] = dz * dz;
@@ -544,11 +554,11 @@ __global__ __launch_bounds__(256) void k_gp_nll_grad(const double* __restrict__ 
 template <int D>
 __global__ void k_gp_nll_matrix(const double* __restrict__ X, int n, double amp, const double* __restrict__ inv_scale, double sigma2,
                                 double* __restrict__ K) {
-    __shared__ double exptab[GP_EXP_N];
+    __shared__ double exptab[GP_EXP_LDS];
     gp_exp_table_to_lds(exptab);
     const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
     if (i >= n) return;
-    double r2 = 1e-300;      // (not 0: matern_terms takes rsq of 3 r2)
+    double r2 = 1e-300;      // (not 0: matern_terms takes rsq of it)
     for (int k = 0; k < D; ++k) {
         const double dz = (X[(long long)i * D + k] - X[(long long)j * D + k]) * inv_scale[k];
         r2 += dz * dz;

@@ -6,7 +6,7 @@
 #include "gp_kernels.hip"
 using namespace gpf;
 __global__ void k(const double* t, double* s, double* e, int n) {
-    __shared__ double tab[GP_EXP_N];
+    __shared__ double tab[GP_EXP_LDS];
     gp_exp_table_to_lds(tab);
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) matern_terms(t[i], s[i], e[i], tab);
