@@ -215,6 +215,14 @@ def run_single(args):
             "workload": f"as the headline workload with a gap that varies in x and y (asperity, num 1) and a cross flow V = 0.05",
             "value": cells * args.steps / w2 / 1e6, "unit": "Mcell-updates/s", "ms_per_step": w2 / args.steps * 1e3,
             "kernel_ms": k2, "roofline": r2, "roofline_achieved_GBps": r2["achieved"], "roofline_frac": r2["frac"], "spread": spread(walls2)}}
+        # BASELINE.json configs[1]: the 2-D inclined slider at 1024^2 (Dirichlet / Neumann edges in x) -- a million
+        # cells, 50 MB per step: the fixed part of a launch (~13 us) is half of it
+        w3, k3, a3, walls3 = time_problem(SLIDER_1024_YAML, max(args.steps, 100), args.warmup)
+        n3 = max(args.steps, 100)
+        out["variants"]["slider_1024x1024"] = {
+            "workload": "2D inclined slider 1024x1024, fixed DH EOS, D/N/N in x, periodic in y, adaptive CFL 0.4 (BASELINE.json configs[1])",
+            "value": 1024 * 1024 * n3 / w3 / 1e6, "unit": "Mcell-updates/s", "ms_per_step": w3 / n3 * 1e3, "steps": n3, "kernel_ms": k3,
+            "roofline_frac": BYTES_PER_CELL_LINE * 1024 * 1024 / (k3 / 1e3) / 1e9 / HBM_PEAK_GBS, "plan": PLAN_NOTES[-1]}
         if not args.no_gp:
             out["variants"]["gp_2048x2048_512pts"] = gp_variant(max(2, min(args.steps, 10)))
             if not args.no_cpu:
@@ -223,6 +231,16 @@ def run_single(args):
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline()
     return out
+
+
+SLIDER_1024_YAML = """
+options: {silent: True, write_freq: 1000000}
+grid: {Nx: 1024, Ny: 1024, Lx: 0.1, Ly: 0.1, xE: ['D', 'N', 'N'], xW: ['D', 'N', 'N'], xE_D: 877.7007, xW_D: 877.7007,
+       yS: ['P', 'P', 'P'], yN: ['P', 'P', 'P']}
+geometry: {type: inclined, hmax: 6.6e-5, hmin: 1.e-5, U: 50., V: 0.}
+numerics: {CFL: 0.4, adaptive: 1, tol: 1.e-12, max_it: 100000000}
+properties: {EOS: DH, shear: 0.0794, bulk: 0., rho0: 877.7007, P0: 101325., C1: 3.5e10, C2: 1.23}
+"""
 
 
 GP_YAML = """
