@@ -205,146 +205,7 @@ static int ensure_stage(gpf_handle* h, size_t doubles) {
     return GPF_OK;
 }
 
-// The buffers the step kernel streams: q[0], q[1], the gap planes, and the candidates plan_placement tries in their place.
-// hipMalloc backs a buffer of this size with a few large, naturally aligned blocks of device memory, so the streams of a launch --
-// rows of three planes 128 MiB-and-a-bit apart, read from one buffer and written to the other at the same offsets -- keep a fixed
-// relation in every address bit above the block offset, and on most boxes of the pool that relation is a bad one: 185-190 us per
-// step where 160-170 are possible, 275 instead of 235 with the gap planes (profiles/r03_placement/scattered_pages.txt; asking for
-// physically contiguous memory makes it worse still: 200-224 us).  So a large field is ONE range of virtual addresses backed by
-// separate physical allocations of 16 MiB mapped in a shuffled order (HIP's virtual memory management): no two streams keep a
-// fixed distance for long.  GPF_SCATTER_MB sets the size of the pieces (0: plain hipMalloc; 2 MiB pieces lose a little to the
-// TLBs, 64 MiB and more leave too few pieces to shuffle); GPF_CONTIGUOUS=1 asks for contiguous memory instead (experiments).
-struct ScatteredField { size_t bytes, part; std::vector<hipMemGenericAllocationHandle_t> parts; };
-static std::mutex& scattered_lock() { static std::mutex m; return m; }
-static std::map<void*, ScatteredField>& scattered_fields() { static std::map<void*, ScatteredField> m; return m; }
-static hipError_t field_malloc_scattered(void** p, size_t bytes, size_t part) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
-    hipMemAllocationProp prop = {};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = dev;
-    size_t gran = 0;
-    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0) return hipErrorNotSupported;
-    part = (part + gran - 1) / gran * gran;
-    const size_t n = (bytes + part - 1) / part, total = n * part;
-    void* va = nullptr;
-    if (hipMemAddressReserve(&va, total, 0, nullptr, 0) != hipSuccess) return hipErrorOutOfMemory;
-    {   // a reservation must not overlap a live one (seen? then say so and leave the virtual-memory path alone)
-        std::lock_guard<std::mutex> g(scattered_lock());
-        for (auto& kv : scattered_fields()) {
-            const char* a0 = (const char*)kv.first; const char* a1 = a0 + kv.second.bytes;
-            if ((const char*)va < a1 && a0 < (const char*)va + total) {
-                std::fprintf(stderr, "[gpf] field_malloc: hipMemAddressReserve returned %p + %zu inside the live range %p + %zu\n", va, total, kv.first, kv.second.bytes);
-                return hipErrorOutOfMemory;
-            }
-        }
-    }
-    ScatteredField f;
-    f.bytes = total; f.part = part;
-    size_t mapped = 0;
-    auto undo = [&]() {
-        for (size_t k = 0; k < mapped; ++k) (void)hipMemUnmap((char*)va + k * part, part);
-        for (auto& hnd : f.parts) (void)hipMemRelease(hnd);
-        (void)hipGetLastError();                             // (the address range stays reserved: see field_free)
-        return hipErrorOutOfMemory;
-    };
-    for (size_t k = 0; k < n; ++k) {
-        hipMemGenericAllocationHandle_t hnd;
-        if (hipMemCreate(&hnd, part, &prop, 0) != hipSuccess) return undo();
-        f.parts.push_back(hnd);
-    }
-    std::vector<size_t> order(n);
-    for (size_t k = 0; k < n; ++k) order[k] = k;
-    unsigned long long x = 0x9e3779b97f4a7c15ull ^ (unsigned long long)(uintptr_t)va;
-    for (size_t k = n - 1; k > 0; --k) {                     // Fisher-Yates with a xorshift generator
-        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
-        std::swap(order[k], order[x % (k + 1)]);
-    }
-    for (size_t k = 0; k < n; ++k) {
-        if (hipMemMap((char*)va + k * part, part, 0, f.parts[order[k]], 0) != hipSuccess) return undo();
-        ++mapped;
-    }
-    hipMemAccessDesc acc = {};
-    acc.location = prop.location;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    if (hipMemSetAccess(va, total, &acc, 1) != hipSuccess) return undo();
-    {
-        std::lock_guard<std::mutex> g(scattered_lock());
-        scattered_fields()[va] = f;
-    }
-    *p = va;
-    return hipSuccess;
-}
-static hipError_t field_malloc(void** p, size_t bytes) {
-    static const bool contiguous = std::getenv("GPF_CONTIGUOUS") && std::atoi(std::getenv("GPF_CONTIGUOUS")) == 1;
-    const int scatter_mb = std::getenv("GPF_SCATTER_MB") ? std::atoi(std::getenv("GPF_SCATTER_MB")) : 16;      // (read per call: A/B handles in one process)
-    if (contiguous && bytes >= (32u << 20)) {
-        if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous) == hipSuccess) return hipSuccess;
-        (void)hipGetLastError();
-    } else if (scatter_mb > 0 && bytes >= ((size_t)scatter_mb << 22)) {          // at least four pieces
-        if (field_malloc_scattered(p, bytes, (size_t)scatter_mb << 20) == hipSuccess) return hipSuccess;
-        (void)hipGetLastError();
-    }
-    return hipMalloc(p, bytes);
-}
-static void field_free(void* p) {
-    if (!p) return;
-    ScatteredField f;
-    {
-        std::lock_guard<std::mutex> g(scattered_lock());
-        auto it = scattered_fields().find(p);
-        if (it == scattered_fields().end()) { (void)hipFree(p); return; }
-        f = it->second;
-        scattered_fields().erase(it);
-    }
-    // The pieces are unmapped and released; the ADDRESS RANGE is not given back.  On this ROCm (7.0 / 7.2) a range that has been
-    // freed and is reserved again reads and writes the wrong memory: of four rounds of "three fields are created, eleven are created,
-    // filled, checked and nine of them freed", 11 of 94 read-backs found a damaged buffer with hipMemAddressFree and none without it,
-    // whichever way the unmapping was done (tools/vmm_probe.hip; here it cost the second of two handles its state:
-    // tests/test_gpu_fullsize.py, flip symmetry).  A reservation costs address space only -- 128 TiB of it per process.
-    int bad = 0;
-    for (size_t k = 0; k < f.parts.size(); ++k) bad += hipMemUnmap((char*)p + k * f.part, f.part) != hipSuccess;
-    for (auto& hnd : f.parts) bad += hipMemRelease(hnd) != hipSuccess;
-    if (bad) { (void)hipGetLastError(); std::fprintf(stderr, "[gpf] field_free: %d call(s) of the virtual-memory API failed for %p\n", bad, p); }
-}
-
-// Copies and fills of whole fields run as kernels on the handle's stream: a field may be a range of virtual addresses made of many
-// separately mapped pieces (field_malloc), and what hipMemcpyAsync / hipMemsetAsync do with such a range across its pieces -- and in
-// which order relative to the stream -- is the runtime's business (tests/test_gpu_fullsize.py lost time steps to a copy that landed
-// after the launches queued behind it).
-__global__ void k_field_copy(double2* __restrict__ dst, const double2* __restrict__ src, size_t n) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
-}
-__global__ void k_field_zero(double2* __restrict__ dst, size_t n) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = double2{0.0, 0.0};
-}
-static int field_copy(hipStream_t s, void* dst, const void* src, size_t bytes) {
-    hipLaunchKernelGGL(k_field_copy, dim3(2048), dim3(256), 0, s, (double2*)dst, (const double2*)src, bytes / sizeof(double2));
-    HIP_TRY(hipGetLastError());
-    return GPF_OK;
-}
-__global__ void k_field_xor(const unsigned long long* __restrict__ p, size_t n, unsigned long long* out) {
-    unsigned long long x = 0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x ^= p[i] * (i | 1);
-    atomicXor(out, x);
-}
-// (diagnostics: GPF_PLACEMENT_PRINT=2 prints a checksum of the state at every stage of the tuner)
-static unsigned long long field_checksum(hipStream_t s, const void* p, size_t bytes) {
-    unsigned long long* d = nullptr; unsigned long long h = 0;
-    if (hipMalloc(&d, 8) != hipSuccess) return 0;
-    (void)hipMemsetAsync(d, 0, 8, s);
-    hipLaunchKernelGGL(k_field_xor, dim3(1024), dim3(256), 0, s, (const unsigned long long*)p, bytes / 8, d);
-    (void)hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, s);
-    (void)hipStreamSynchronize(s);
-    (void)hipFree(d);
-    return h;
-}
-static int field_zero(hipStream_t s, void* dst, size_t bytes) {
-    hipLaunchKernelGGL(k_field_zero, dim3(2048), dim3(256), 0, s, (double2*)dst, bytes / sizeof(double2));
-    HIP_TRY(hipGetLastError());
-    return GPF_OK;
-}
+#include "api_fields.inc"
 
 extern "C" int gpf_create(const gpf_config* cfg, gpf_handle** out) {
     if (!cfg || !out) return fail(GPF_ERR_INVALID, "gpf_create: null argument");
@@ -849,315 +710,7 @@ static Strip2Geom strip2_geom(const Layout& L, int D) {
 // slab).  GPF_STEP_UNFUSED_EDGES=1 at gpf_create selects the older split form instead, kept as a cross-check.
 static bool step2_fused(const gpf_handle* h) { return !h->split_edges; }
 
-constexpr int K2_LONG_MARCH_ROWS = 100;    // rows per wave from which plan_step2 runs one wave per SIMD instead of two
-
-// One wave marches over one row chunk of one 126-column strip; the chunks are sized so that all waves are resident at
-// once (a single round, no tail) when the problem is big enough: two waves per SIMD, or one.
-static int plan_apply(gpf_handle* h, int nchunks, int nt) {
-    const Layout& L = h->L;
-    const int nstrips = std::max(h->geom2[0].nstrips, h->geom2[1].nstrips);
-    nchunks = std::max(1, std::min(nchunks, std::max(1, L.Nx / 4)));        // small grids: >= 4 rows per chunk
-    h->nchunks2 = nchunks;
-    h->nt_policy2 = nt;
-    const int nwaves = nstrips * nchunks;
-    h->nblocks2 = (((nwaves + 3) / 4) + 7) / 8 * 8;
-    if (nwaves > h->npartials2_cap) {
-        if (h->partials) HIP_TRY(hipFree(h->partials));
-        h->partials = nullptr;
-        HIP_TRY(hipMalloc(&h->partials, (size_t)nwaves * sizeof(Partial)));
-        HIP_TRY(hipMemset(h->partials, 0, (size_t)nwaves * sizeof(Partial)));
-        h->npartials2_cap = nwaves;
-    }
-    if (h->nblocks2 > h->nblock_partials_cap) {
-        const int cap = std::max(1024, h->nblocks2);
-        if (h->block_partials) HIP_TRY(hipFree(h->block_partials));
-        h->block_partials = nullptr;
-        HIP_TRY(hipMalloc(&h->block_partials, (size_t)cap * sizeof(Partial)));
-        h->nblock_partials_cap = cap;
-    }
-    return GPF_OK;
-}
-
-static void fill_step2_args(gpf_handle* h, Step2Args& a2, int D, int honor_stop, long long log_base, double* slab_out, bool p2p);
-
-// Mean duration (us) of the fused step with the plan in force, on the handle's own field: the launches read the current state and
-// write the OTHER buffer (dead until the next step overwrites it) and commit into a copy of the run state, which is reset before
-// every launch -- nothing the solver will read changes.  `both`: every other launch runs the other way round, reading what the
-// launch before has written and overwriting the current state (a step reads q[0] and writes q[1], the next one q[1] and q[0], and
-// the two can differ by 10 %: it is the buffer WRITTEN that counts); the state is restored from h->plan_master afterwards.
-static int plan_trial(gpf_handle* h, int D, float* us, int reps = 6, bool both = false) {
-    static const int parity_value[2] = {0, 1};
-    if (!h->st_trial) HIP_TRY(hipMalloc(&h->st_trial, sizeof(StepState)));
-    h->prev_state_valid = false;            // the launches below overwrite the other buffer
-    both = both && h->plan_master != nullptr;
-    int par = 0;
-    if (both) GPF_TRY(current_parity(h, &par));
-    Step2Args a2;
-    fill_step2_args(h, a2, D, 0, 0, nullptr, false);
-    a2.st = h->st_trial; a2.log = nullptr;
-    const step2_kernel_t k2 = step2_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, D, topo_mode_of(h));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    float total = 0.f;
-    for (int r = -1; r < reps; ++r) {       // r = -1: warm-up, not timed
-        HIP_TRY(hipMemcpyAsync(h->st_trial, h->st, sizeof(StepState), hipMemcpyDeviceToDevice, h->stream));
-        if (both && ((r + 1) & 1))
-            HIP_TRY(hipMemcpyAsync(&h->st_trial->parity, &parity_value[par ^ 1], sizeof(int), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipEventRecord(e0, h->stream));
-        hipLaunchKernelGGL(k2, dim3(h->nblocks2), dim3(256), 0, h->stream, a2, h->P);
-        HIP_TRY(hipEventRecord(e1, h->stream));
-        HIP_TRY(hipEventSynchronize(e1));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        if (r >= 0) total += ms;
-    }
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    if (both) GPF_TRY(field_copy(h->stream, h->q[par], h->plan_master, h->field_bytes));
-    HIP_TRY(hipGetLastError());
-    *us = total / reps * 1e3f;
-    return GPF_OK;
-}
-
-// WHERE the fields lie in device memory.  The same kernel on the same device runs at two speeds -- e.g. 167 or 183 us at 4096^2,
-// 234 or 275 us with the gap planes -- depending on which physical pages the allocator happened to hand out for the buffers it
-// reads and writes: twelve identical handles of one process, with identical virtual layouts, split 1 : 11 in one run and 5 : 7 in
-// another, each handle keeping its speed for as long as it lives (tools/ab_inprocess.py, profiles/r03_placement/).  Offsets between
-// the buffers, one allocation instead of three and the plane stride were scanned without finding the rule, and physically
-// contiguous memory is the slowest of all, so large grids do what the plan does: they TRY.  A few spare buffers join the handle's own
-// in a pool.  Most of what distinguishes the buffers shows when they are WRITTEN (profiles/r03_placement/pair_matrices.txt: one
-// column of the read x written matrix stands out, not one row), so the step is first timed writing each buffer of the pool in
-// turn; then, for the best four, for every ordered (read, written) pair -- a step reads one state buffer and writes the other, the
-// next one the other way round, so a pair's figure is the sum of both directions.  The best pair becomes the handle's memory, then
-// (kernels that read the gap planes) the best home among a few of the remaining buffers for those; the rest is freed.  With S spares:
-// S + 2 + 12 trials of 7 launches and S + 1 buffers of transient memory (whole triples, as first tried: S trials for 3 S buffers).
-// GPF_PLACEMENT_TRIES sets S (default: 24, and twelve more for as long as the last twelve still paid, up to 60 -- on one box 10 / 30 / 60
-// spares ended at 155.1, 152.6 / 151.1, 151.4 / 150.9 us per step in separate processes; 0: keep the handle's own buffers);
-// GPF_PLACEMENT_PRINT=1 prints the figures.
-static int plan_placement(gpf_handle* h, int D, std::string& note) {
-    const char* env_tries = std::getenv("GPF_PLACEMENT_TRIES");
-    const int fixed = env_tries ? std::atoi(env_tries) : -1;            // -1: two batches of 12, then on while a batch still pays
-    if (fixed == 0 || !h->plan_master) return GPF_OK;
-    const bool print = std::getenv("GPF_PLACEMENT_PRINT") && std::atoi(std::getenv("GPF_PLACEMENT_PRINT")) != 0;
-    int par = 0;
-    GPF_TRY(current_parity(h, &par));
-    const bool planes = topo_mode_of(h) == 0;               // the kernel reads h->topo (otherwise the gap travels as a line)
-    double* const master = h->plan_master;                  // the current state, never a candidate
-    std::vector<double*> pool = {h->q[par], h->q[par ^ 1]};
-    std::vector<char> holds_state = {1, 0};
-    std::vector<float> w = {0.f, 0.f};
-    // read pool[i], write pool[j]; `both`: and the other way round in every other launch (plan_trial restores the state in pool[i])
-    auto trial = [&](int i, int j, float* us, bool both) -> int {
-        if (!holds_state[i]) {
-            GPF_TRY(field_copy(h->stream, pool[i], master, h->field_bytes));
-            holds_state[i] = 1;
-        }
-        holds_state[j] = 0;
-        h->q[par] = pool[i]; h->q[par ^ 1] = pool[j];
-        return plan_trial(h, D, us, 6, both);
-    };
-    // phase 1: every buffer as the one WRITTEN (the state read from the handle's own buffer; that one is written reading its twin) --
-    // most of what distinguishes the buffers shows there (profiles/r03_placement/pair_matrices.txt).  The spares come in batches of
-    // twelve, all held to the end (freed memory comes straight back): two batches, then another one for as long as the last one
-    // lowered the best figure by more than 1 % (at most five; GPF_PLACEMENT_TRIES=n: n spares, no more, no less).
-    float best_w = 0.f;
-    for (int round = 0; round < (fixed > 0 ? 1 : 5); ++round) {
-        int want = fixed > 0 ? fixed : 12;
-        size_t free_b = 0, total_b = 0;
-        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        while (want > 0 && (size_t)want * h->field_bytes + (2ull << 30) > free_b) --want;
-        const size_t first = pool.size();
-        for (int k = 0; k < want; ++k) {
-            double* b = nullptr;
-            if (field_malloc((void**)&b, h->field_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-            GPF_TRY(field_zero(h->stream, b, h->field_bytes));
-            pool.push_back(b); holds_state.push_back(0); w.push_back(0.f);
-        }
-        if (pool.size() == first) break;
-        float batch_best = 0.f;
-        for (size_t k = first; k < pool.size(); ++k) {
-            GPF_TRY(trial(0, (int)k, &w[k], false));
-            if (batch_best == 0.f || w[k] < batch_best) batch_best = w[k];
-        }
-        const bool paid = best_w == 0.f || batch_best < 0.99f * best_w;
-        if (best_w == 0.f || batch_best < best_w) best_w = batch_best;
-        if (round >= 1 && !paid) break;
-    }
-    const int n = (int)pool.size();
-    if (n == 2) return GPF_OK;
-    GPF_TRY(trial(0, 1, &w[1], false));                     // the handle's own two: each written reading the other
-    GPF_TRY(trial(1, 0, &w[0], false));
-    std::vector<int> order(n);
-    for (int k = 0; k < n; ++k) order[k] = k;
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return w[x] < w[y]; });
-    // phase 2: the pairs of the best few and the handle's own pair, both directions of the step in each trial
-    const int m = std::min(n, 4);
-    float own_pair = 0.f;
-    GPF_TRY(trial(0, 1, &own_pair, true));
-    int bi = 0, bj = 1;
-    float best = own_pair, worst = own_pair;
-    std::string pairs;
-    for (int i = 0; i < m; ++i)
-        for (int j = i + 1; j < m; ++j) {
-            const int x = std::min(order[i], order[j]), y = std::max(order[i], order[j]);
-            if (x == 0 && y == 1) continue;
-            float t = 0.f;
-            GPF_TRY(trial(x, y, &t, true));
-            if (print) { char b2[40]; std::snprintf(b2, sizeof b2, " (%d,%d) %.1f", x, y, t); pairs += b2; }
-            if (t < best) { best = t; bi = x; bj = y; }
-            worst = std::max(worst, t);
-        }
-    if (print) {
-        std::fprintf(stderr, "[gpf] placement: us per step writing each buffer (0, 1: the handle's own):");
-        for (int k = 0; k < n; ++k) std::fprintf(stderr, " %.1f", w[k]);
-        std::fprintf(stderr, "\n[gpf] placement: pairs, both directions: (0,1) %.1f%s\n", own_pair, pairs.c_str());
-    }
-    char buf[200];
-    std::snprintf(buf, sizeof buf, " placement: %d buffers, written %.0f .. %.0f us, pair kept %.0f, the handle's own %.0f", n,
-                  *std::min_element(w.begin(), w.end()), *std::max_element(w.begin(), w.end()), best, own_pair);
-    note = buf;
-    std::vector<double*> rest;
-    for (int k = 0; k < n; ++k) if (k != bi && k != bj) rest.push_back(pool[k]);
-    float us = 0.f;
-    if (planes) {
-        // the gap planes: their present home or one of the buffers left over
-        double* const own = h->topo;
-        double* best_home = own;
-        float best_t = 0.f;
-        std::string seen;
-        for (size_t k = 0; k <= std::min<size_t>(rest.size(), 3); ++k) {
-            double* cand = k == 0 ? own : rest[k - 1];
-            if (cand != own) GPF_TRY(field_copy(h->stream, cand, own, h->field_bytes));
-            h->topo = cand;
-            float t = 0.f;
-            GPF_TRY(trial(bi, bj, &t, true));
-            std::snprintf(buf, sizeof buf, " %.0f", t);
-            seen += buf;
-            if (k == 0 || t < best_t) { best_t = t; best_home = cand; }
-        }
-        note += "; gap planes:" + seen;
-        if (best_home != own) {
-            rest.erase(std::find(rest.begin(), rest.end(), best_home));
-            rest.push_back(own);
-        }
-        h->topo = best_home;
-    }
-    GPF_TRY(trial(bi, bj, &us, true));                      // leaves the state in pool[bi] = q[par]
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    for (double* b : rest) field_free(b);
-    h->q[par] = pool[bi]; h->q[par ^ 1] = pool[bj];
-    return GPF_OK;
-}
-
-// Which plan: waves per SIMD (row chunks per strip) and the cache policy of the stores.  Neither has a winner that holds across
-// kernels and boxes (paired in-process runs at 4096^2, tools/ab_inprocess.py: the x-only-gap kernel is 2-3 % faster with two
-// waves per SIMD and indifferent to the store policy, the 2-D-gap kernel 6 % faster with one wave per SIMD AND non-temporal
-// stores, 4 % with two waves and plain ones; round 2's runs on other boxes favoured one wave per SIMD for both), so grids of a
-// million cells and more TIME the candidates once, on their own data (plan_trial: ~8 ms per handle), and keep the fastest.
-// Smaller grids and GPF_PLAN_TUNE=0 take the rule of thumb; GPF_CHUNKS / GPF_NT_STORES pin a choice (A/B runs).
-static const char* const NT_NAME[3] = {"plain loads and stores", "non-temporal stores", "non-temporal loads and stores"};
-static int plan_step2(gpf_handle* h, int D) {
-    if (h->plan2_valid) return GPF_OK;
-    const Layout& L = h->L;
-    h->geom2[0] = strip2_geom(L, 1);
-    h->geom2[1] = strip2_geom(L, -1);
-    const int nstrips = std::max(h->geom2[0].nstrips, h->geom2[1].nstrips);
-    int per_cu = 0, ncu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)step2_kernel(h->cfg.eos, h->Ls != nullptr, h->cfg.piezo != 0, 1, topo_mode_of(h)), 256, 0));
-    HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->cfg.device));
-    const int all_resident = std::max(1, std::max(1, per_cu * ncu) * 4 / nstrips);      // every wave resident in one round (two per SIMD)
-    const int one_per_simd = (ncu * 4) / nstrips;
-    // Non-temporal stores can only pay where a step streams more than the 256-MiB Infinity Cache holds (q read + q written + the
-    // topography planes if they are read); below that the previous step's output is still on the die when the next step loads it.
-    const double streamed = (double)L.plane * 8.0 * (6 + (topo_mode_of(h) == 0 ? 3 : 0) + (h->Ls ? 1 : 0));
-    const bool nt_possible = streamed > 192.0 * 1024 * 1024;
-    const char* env_chunks = std::getenv("GPF_CHUNKS");
-    const char* env_nt = std::getenv("GPF_NT") ? std::getenv("GPF_NT") : std::getenv("GPF_NT_STORES");      // 0, 1 (stores), 2 (stores and loads)
-    const char* env_tune = std::getenv("GPF_PLAN_TUNE");
-    // rule of thumb: one wave per SIMD for long marches (>= 100 rows per wave), non-temporal stores where they can pay
-    int nchunks = all_resident;
-    if (one_per_simd >= 1 && L.Nx / one_per_simd >= K2_LONG_MARCH_ROWS) nchunks = one_per_simd;
-    int nt = nt_possible ? 2 : 0;
-    if (env_chunks && std::atoi(env_chunks) > 0) nchunks = std::atoi(env_chunks);
-    if (env_nt) nt = std::max(0, std::min(2, std::atoi(env_nt)));
-    // (a slab tunes like any other handle: the trial launches commit into the scratch state and send nothing)
-    const bool tune = !(env_tune && std::atoi(env_tune) == 0) && !h->split_edges && h->pre_run_done && (long long)L.Nx * L.Ny >= (1ll << 20) &&
-                      one_per_simd >= 1 && L.Nx / one_per_simd >= 16 && !(env_chunks && env_nt);
-    if (!tune) {
-        GPF_TRY(plan_apply(h, nchunks, nt));
-        std::snprintf(h->plan2_note, sizeof h->plan2_note, "%d chunks per strip, %s (rule of thumb%s)", h->nchunks2,
-                      NT_NAME[h->nt_policy2], (env_chunks || env_nt) ? ", pinned by the environment" : "");
-        h->plan2_valid = true;
-        return GPF_OK;
-    }
-    std::string placement_note;
-    GPF_TRY(plan_apply(h, nchunks, nt));
-    {   // a copy of the state: trials that run the step both ways overwrite it (plan_trial)
-        int par = 0;
-        GPF_TRY(current_parity(h, &par));
-        if (field_malloc((void**)&h->plan_master, h->field_bytes) == hipSuccess)
-            GPF_TRY(field_copy(h->stream, h->plan_master, h->q[par], h->field_bytes));
-        else { (void)hipGetLastError(); h->plan_master = nullptr; }
-    }
-    {   // The trials come after an idle stretch (the host has just built the problem) and the device takes ~10 ms of load to reach its
-        // running clocks: the first candidates of a scan read 5-10 % slow (profiles/r03_placement/README.md).  Load it first.
-        float unused = 0.f;
-        const double step_s = 1.1e-11 * (double)L.Nx * L.Ny + 1e-5;    // roughly what a launch takes
-        GPF_TRY(plan_trial(h, D, &unused, (int)std::min(200.0, std::max(8.0, 0.012 / step_s))));
-    }
-    float best = 0.f;
-    int best_chunks = nchunks;
-    int best_nt = nt;
-    std::string seen;
-    auto pick_plan = [&]() -> int {
-        best = 0.f;
-        seen.clear();
-        for (int c : {one_per_simd, all_resident}) {
-            if (env_chunks && std::atoi(env_chunks) > 0) c = std::atoi(env_chunks);
-            for (int pol = 0; pol < (nt_possible && !env_nt ? 3 : 1); ++pol) {
-                const int cand_nt = env_nt ? nt : pol;
-                GPF_TRY(plan_apply(h, c, cand_nt));
-                float us = 0.f;
-                GPF_TRY(plan_trial(h, D, &us, 6, true));
-                char buf[48];
-                std::snprintf(buf, sizeof buf, " %d/%s %.0f", h->nchunks2, cand_nt == 2 ? "nt" : cand_nt == 1 ? "nts" : "plain", us);
-                seen += buf;
-                if (best == 0.f || us < best) { best = us; best_chunks = c; best_nt = cand_nt; }
-            }
-            if ((env_chunks && std::atoi(env_chunks) > 0) || one_per_simd == all_resident) break;
-        }
-        return plan_apply(h, best_chunks, best_nt);
-    };
-    // the plan on the memory the handle has, the memory under that plan (which pages are good depends on how many streams run),
-    // the plan once more on the memory kept
-    const bool verify = std::getenv("GPF_PLACEMENT_PRINT") && std::atoi(std::getenv("GPF_PLACEMENT_PRINT")) >= 2;
-    auto stamp = [&](const char* when) {
-        if (!verify) return;
-        int par = 0;
-        if (current_parity(h, &par) != GPF_OK) return;
-        std::fprintf(stderr, "[gpf] %-28s q[par] %p %016llx   master %p %016llx\n", when, (void*)h->q[par], field_checksum(h->stream, h->q[par], h->field_bytes),
-                     (void*)h->plan_master, h->plan_master ? field_checksum(h->stream, h->plan_master, h->field_bytes) : 0ull);
-    };
-    stamp("before the first plan");
-    GPF_TRY(pick_plan());
-    stamp("after the first plan");
-    const std::string first_seen = seen;
-    GPF_TRY(plan_placement(h, D, placement_note));
-    stamp("after the placement");
-    if (!placement_note.empty()) GPF_TRY(pick_plan());
-    stamp("after the second plan");
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    field_free(h->plan_master);
-    h->plan_master = nullptr;
-    GPF_TRY(plan_apply(h, best_chunks, best_nt));
-    std::snprintf(h->plan2_note, sizeof h->plan2_note, "%d chunks per strip, %s (timed, us:%s;%s%s%s)", h->nchunks2,
-                  NT_NAME[h->nt_policy2], seen.c_str(), placement_note.c_str(),
-                  placement_note.empty() ? "" : "; before the placement:", placement_note.empty() ? "" : first_seen.c_str());
-    DBG("plan_step2: %s", h->plan2_note);
-    h->plan2_valid = true;
-    return GPF_OK;
-}
-
-extern "C" const char* gpf_plan_note(gpf_handle* h) { return h ? h->plan2_note : ""; }
+#include "api_plan.inc"
 
 #ifndef GPF_SLAB_COMMIT_BLOCKS
 #define GPF_SLAB_COMMIT_BLOCKS 24

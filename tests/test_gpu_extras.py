@@ -199,7 +199,7 @@ np.savez(sys.argv[1], **out)
 
 
 def test_large_fields_come_back_whole_after_other_handles_are_destroyed(hiplib):
-    """Large fields are ranges of virtual addresses backed by shuffled 16-MiB pieces of device memory (csrc/api.hip: field_malloc),
+    """Large fields are ranges of virtual addresses backed by shuffled 16-MiB pieces of device memory (csrc/api_fields.inc: field_malloc),
     and the placement search allocates and returns a dozen of them per handle.  Handles are created, stepped and destroyed in
     turn: every one of a set of identical problems must produce the same bits -- a range returned with a live mapping inside
     would hand the next field another field's pages -- and the device memory in use must return to where it started."""

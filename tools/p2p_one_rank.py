@@ -1,7 +1,7 @@
 """Per-step latency of the slab step on ONE rank: all-gather transport vs peer-to-peer transport, for the whole
 4096^2 grid and for one eighth of it (what a rank owns at 8 GPUs), each in the arrangements the library offers:
 
-    (default)     k_step2 + k_begin_slab per step, plan and placement as the handle times them (csrc/api.hip: plan_step2)
+    (default)     k_step2 + k_begin_slab per step, plan and placement as the handle times them (csrc/api_plan.inc: plan_step2)
     notune        GPF_PLAN_TUNE=0: rule-of-thumb plan, first placement
     chunks=N      GPF_CHUNKS=N: N row chunks per strip instead of what plan_step2 picks
 (the `folded` / `every-step` pair of profiles/r03_slab/ was measured with the patch kept there)

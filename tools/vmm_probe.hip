@@ -1,5 +1,5 @@
 // Does HIP's virtual memory management keep buffers apart under the allocation pattern of gapflow_amd's scattered fields
-// (csrc/api.hip: field_malloc)?  Buffers = one reserved address range each, backed by separately created 16-MiB pieces mapped in
+// (csrc/api_fields.inc: field_malloc)?  Buffers = one reserved address range each, backed by separately created 16-MiB pieces mapped in
 // a shuffled order; set A and set B are created and filled with patterns, A is freed, set C is created and filled; then B and C
 // are read back.      hipcc --offload-arch=gfx950 -O2 tools/vmm_probe.hip -o /tmp/vmm_probe && /tmp/vmm_probe [unmap-whole]
 #include <hip/hip_runtime.h>
