@@ -36,14 +36,15 @@ namespace gpf {
 
 constexpr int STRIP2 = 126;     // output columns per wavefront
 #ifndef GPF_K2_AHEAD
-#define GPF_K2_AHEAD 2          // rows requested ahead of the one being computed (1 .. 4)
+#define GPF_K2_AHEAD 2          // rows requested ahead of the one being computed (1 .. 6)
 #endif
 #ifndef GPF_K2_AHEAD_LINE
 #define GPF_K2_AHEAD_LINE 4     // ... for the x-only-gap kernels: three loads per row instead of six, so two rows ahead keep only
                                 // 6 KB per wave in flight -- with one wave per SIMD (long marches, plan_step2) less than the
                                 // bandwidth-latency product; 4 rows measured 1.7 % faster there, equal elsewhere.  (3 is unusable:
                                 // with four row buffers hipcc renames them across the back edge and copies registers whose
-                                // loads are in flight -- tools/audit_step_isa.py reports it.)
+                                // loads are in flight -- tools/audit_step_isa.py reports it; so is 5.  6 is clean -- 238 registers, two
+                                // waves per SIMD still -- and buys nothing: 154.9 / 156.7 against 153.9 / 152.8 us, paired handles.)
 #endif
 #ifndef GPF_K2_MINWAVES
 #define GPF_K2_MINWAVES 2       // waves per SIMD the register allocation is held to
@@ -475,13 +476,15 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
     // buffer, so no register copies are needed to advance the window.
     // (the piezo-viscosity closures -- exp / pow per cell -- leave no registers for the third buffer: one row ahead there)
     constexpr int AHEAD = AHEAD_ROWS;
-    static_assert(AHEAD >= 1 && AHEAD <= 4, "1 to 4 rows ahead");
+    static_assert(AHEAD >= 1 && AHEAD <= 6, "1 to 6 rows ahead");
     constexpr int NB = AHEAD + 1;
     Raw rowbuf[NB];
     issue(n_first - 1, rowbuf[0]);
     if (AHEAD >= 2) issue(n_first, rowbuf[1 % NB]);
     if (AHEAD >= 3) issue(n_first + 1, rowbuf[2 % NB]);
     if (AHEAD >= 4) issue(n_first + 2, rowbuf[3 % NB]);
+    if (AHEAD >= 5) issue(n_first + 3, rowbuf[4 % NB]);
+    if (AHEAD >= 6) issue(n_first + 4, rowbuf[5 % NB]);
 
     // carried from the previous row, per slot
     double fx1p[2][3] = {{0, 0, 0}, {0, 0, 0}};     // stage-1 x-flux of row n-1
@@ -625,6 +628,8 @@ __device__ __forceinline__ void step_strip2(const Step2Args& a, const Phys& P, c
         if (AHEAD >= 2) { march(n, rowbuf[2 % NB], rowbuf[1]); if (++n > n_last + 1) break; }
         if (AHEAD >= 3) { march(n, rowbuf[3 % NB], rowbuf[2 % NB]); if (++n > n_last + 1) break; }
         if (AHEAD >= 4) { march(n, rowbuf[4 % NB], rowbuf[3 % NB]); if (++n > n_last + 1) break; }
+        if (AHEAD >= 5) { march(n, rowbuf[5 % NB], rowbuf[4 % NB]); if (++n > n_last + 1) break; }
+        if (AHEAD >= 6) { march(n, rowbuf[6 % NB], rowbuf[5 % NB]); if (++n > n_last + 1) break; }
     }
     // The last requests (repeats of the final row) are still in flight: drain them while the buffers are still
     // live, or a late return would land in registers the code below has reused.
